@@ -1,0 +1,165 @@
+/* slam_hip.h — C ABI of libslam_hip.so, the MI355X (gfx950) particle-filter step.
+ *
+ * The reference (ferasboulala/slam) has no FFI or plugin layer: its boundary for this path is the
+ * statically linked C++ class slam::MCL (slam/mcl.h:12-46) plus the free functions of
+ * slam/motion.h:9-11 and slam/raycast.h:13-28.  This header is what a C++ shim of that class (see
+ * slam_amd/host/ and INTEGRATION.md) binds instead of the CPU implementation in slam/mcl.cpp.
+ * Every entry point cites the reference code it replaces.
+ *
+ * Conventions: plain C types; caller-allocated buffers; host pointers unless a name ends in
+ * _dev; int status return (0 = ok, negative = error, text from slam_last_error()); no exceptions
+ * cross the boundary; a handle is used from one thread at a time; every call is complete
+ * (synchronised) on return unless documented otherwise.  Particle state stays resident in HBM
+ * between calls.
+ */
+#ifndef SLAM_HIP_H
+#define SLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slam_mcl slam_mcl;
+
+enum
+{
+    SLAM_OK = 0,
+    SLAM_ERR_ARG = -1,     /* bad argument (NULL, non-finite pose, size mismatch) */
+    SLAM_ERR_HIP = -2,     /* a HIP runtime call failed */
+    SLAM_ERR_STATE = -3,   /* call not valid in this mode / before a map was set */
+    SLAM_ERR_NOMEM = -4
+};
+
+enum { SLAM_MODE_LOCALIZATION = 0, SLAM_MODE_SLAM = 1 };
+enum { SLAM_NOISE_PHILOX = 0, SLAM_NOISE_INJECTED = 1 };
+enum { SLAM_PREFIX_BLOCKED = 0, SLAM_PREFIX_REFERENCE = 1 };
+enum { SLAM_RESAMPLE_MULTINOMIAL = 0, SLAM_RESAMPLE_SYSTEMATIC = 1 };
+enum { SLAM_SORT_FULL = 0, SLAM_SORT_NONE = 1 };
+enum { SLAM_RAYCAST_FAST = 0, SLAM_RAYCAST_WALK = 1 };
+
+/* Construction parameters.  Zero-initialise, set struct_size = sizeof(slam_mcl_params), fill in.
+ * Replaces the constructor arguments of slam::MCL (slam/mcl.h:15, slam/mcl.cpp:16-39). */
+typedef struct slam_mcl_params
+{
+    int32_t struct_size;
+    int32_t mode;          /* SLAM_MODE_SLAM: one uint8 canvas per particle, updated along every
+                              ray — exactly slam::MCL.  SLAM_MODE_LOCALIZATION: one shared
+                              read-only map (SURVEY.md §8a row aL). */
+    int64_t n_particles;   /* particles held by THIS handle (one shard) */
+    int32_t rows, cols;    /* canvas size (SLAM) or map size (localization) */
+    int32_t device;        /* HIP device ordinal */
+    int32_t noise;         /* SLAM_NOISE_*: where the normal/uniform streams come from */
+    uint64_t seed;         /* Philox key */
+    int32_t prefix_order;  /* SLAM_PREFIX_BLOCKED: canonical radix-64 blocked order (parallel,
+                              independent of GPU count); SLAM_PREFIX_REFERENCE: the reference's
+                              sequential running sum (slam/mcl.cpp:170-176), one thread */
+    int32_t resampler;     /* SLAM_RESAMPLE_MULTINOMIAL is the reference's rule */
+    int32_t sort;          /* SLAM_SORT_FULL keeps the reference's post-update invariant
+                              (slam/mcl.cpp:236-238); order is (weight desc, slot asc) */
+    int32_t raycaster;     /* SLAM_RAYCAST_FAST: clearance-skipping walk (localization only);
+                              SLAM_RAYCAST_WALK: cell-by-cell walk, counts cells */
+    int64_t global_first;  /* index of this shard's first particle in the whole filter */
+    int64_t global_n;      /* particles in the whole filter (0 = n_particles) */
+    void* stream;          /* hipStream_t to launch on (NULL = the null stream) */
+} slam_mcl_params;
+
+const char* slam_last_error(void);
+int slam_version(void);
+
+/* slam::MCL::MCL + reset_particles (slam/mcl.cpp:16-39): SLAM mode starts every particle at the
+ * canvas centre (cols/2, rows/2, pi/2), weight 1/N, canvas filled with 128.  Localization mode
+ * starts with the same poses and no map (set one, then seed). */
+int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out);
+void slam_mcl_destroy(slam_mcl* h);
+
+/* Localization mode: the shared occupancy grid, row-major uint8, hit test `< 128` as in
+ * slam/raycast.cpp:183-184.  Builds the clearance grid used by SLAM_RAYCAST_FAST. */
+int slam_mcl_set_map_u8(slam_mcl* h, const uint8_t* map, int32_t rows, int32_t cols);
+
+/* Particle seeding / direct state access (no reference counterpart beyond reset_particles). */
+int slam_mcl_set_poses(slam_mcl* h, const double* x, const double* y, const double* theta, int64_t first, int64_t count);
+int slam_mcl_seed_gaussian(slam_mcl* h, const double mean[3], const double sigma[3]);
+int slam_mcl_seed_uniform_free(slam_mcl* h);
+int slam_mcl_set_maps_u8(slam_mcl* h, const uint8_t* maps, int64_t first, int64_t count); /* SLAM mode */
+
+/* Noise injection (SLAM_NOISE_INJECTED): unit normals z[3*n_particles] consumed by the next
+ * predict (order rotation_1, translation, rotation_2 per particle: slam/motion.cpp:13-25) and
+ * canonical uniforms c[n_particles] consumed by the next update (slam/mcl.cpp:181).  Either
+ * pointer may be NULL to leave that stream unchanged. */
+int slam_mcl_set_noise(slam_mcl* h, const double* unit_normals, const double* canonical_uniforms);
+
+/* slam::MCL::predict (slam/mcl.cpp:41-47) = sample_motion_model_odometry (slam/motion.cpp:9-32)
+ * for every particle.  odom = {rotation_1, translation, rotation_2}. */
+int slam_mcl_predict(slam_mcl* h, const double odom[3], const double alphas[4]);
+
+/* slam::MCL::update (slam/mcl.cpp:102-145): weights from raycast_mapping + measurement_model_beam
+ * (slam/raycast.cpp:143-242, slam/mcl.cpp:49-78), then resample_particles (slam/mcl.cpp:157-239).
+ * scan is (angle, dist) per beam as built by the callers (benchmark/mcl.cpp:37-56). */
+int slam_mcl_update(slam_mcl* h, const double* angles, const double* dists, int32_t n_beams, double stddev,
+                    double max_dist, const double scanner_offset[3]);
+
+/* The two halves of update, for sharded (multi-GPU) drivers and tests. */
+int slam_mcl_update_weights(slam_mcl* h, const double* angles, const double* dists, int32_t n_beams, double stddev,
+                            double max_dist, const double scanner_offset[3]);
+int slam_mcl_resample(slam_mcl* h);
+
+/* Read-back (replaces get_particles(), slam/mcl.h:26). */
+int slam_mcl_get_poses(slam_mcl* h, double* x, double* y, double* theta, int64_t first, int64_t count);
+int slam_mcl_get_weights(slam_mcl* h, double* w, int64_t first, int64_t count);
+int slam_mcl_get_map_u8(slam_mcl* h, int64_t particle, uint8_t* map);      /* SLAM mode */
+int slam_mcl_get_last_indices(slam_mcl* h, int32_t* idx);                  /* selection before the sort */
+int slam_mcl_get_last_order(slam_mcl* h, int32_t* perm);                   /* sort permutation */
+int slam_mcl_get_prefix(slam_mcl* h, double* prefix, double* sum);        /* running sum used by the last resample */
+int slam_mcl_get_hits(slam_mcl* h, double* hit_xy, int32_t* hit_cell);    /* per particle-beam, last update_weights;
+                                                                              recorded only after slam_mcl_record_hits(h, 1) */
+int slam_mcl_record_hits(slam_mcl* h, int32_t enable);
+/* slam::average_pose (slam/util.cpp:66-85) reduced on the device. */
+int slam_mcl_average_pose(slam_mcl* h, double out[3]);
+/* Counters of the last update_weights: {cells read, cells written, steps}; SLAM_RAYCAST_WALK and SLAM mode only. */
+int slam_mcl_get_stats(slam_mcl* h, int64_t out[3]);
+/* Accumulated device time (HIP events on the handle's stream) per kernel group since the last
+ * reset: out[0] predict, [1] weights, [2] resample (scan+select+gather), [3] sort, [4] map clone;
+ * launches[k] = number of launches accumulated.  Enable with slam_mcl_profile(h, 1). */
+int slam_mcl_profile(slam_mcl* h, int32_t enable);
+int slam_mcl_get_kernel_ms(slam_mcl* h, double ms[5], int64_t launches[5], int32_t reset);
+
+/* Device pointers of the resident state (for RCCL collectives issued by the caller). */
+typedef struct slam_mcl_device_state
+{
+    double* x_dev;
+    double* y_dev;
+    double* theta_dev;
+    double* weight_dev;
+    double* prefix_dev;      /* n_particles inclusive running sums */
+    double* chunk_totals_dev;/* ceil(n/64) totals of the level-0 chunks */
+    int64_t n_particles;
+} slam_mcl_device_state;
+int slam_mcl_device_state_get(slam_mcl* h, slam_mcl_device_state* out);
+
+/* Sharded resampling, used by one-process-per-GPU drivers:
+ *  1. slam_mcl_shard_scan: level-0 chunk scans of the local weights -> chunk totals (device).
+ *  2. caller all-gathers chunk totals, poses and weights of all shards (RCCL).
+ *  3. slam_mcl_shard_select: builds the global running sum in the canonical blocked order from
+ *     the gathered chunk totals + gathered weights, draws this shard's slots, and gathers the
+ *     selected particles from the gathered state into this shard.  All *_dev arrays have
+ *     global_n entries (chunk totals: ceil(global_n/64)). */
+int slam_mcl_shard_scan(slam_mcl* h);
+int slam_mcl_shard_select(slam_mcl* h, const double* all_x_dev, const double* all_y_dev, const double* all_theta_dev,
+                          const double* all_w_dev);
+
+/* FakeLidar::scan (slam/fake_lidar.cpp:15-33) + raycast<int> (slam/raycast.cpp:100-141), batched
+ * on the device: n_poses sensor poses x n_rays rays on a CV_32S-style map given as uint8 (0 = wall).
+ * hits_xy[(p*n_rays + r)*2 ..] = hit position or (-1,-1). */
+int slam_fake_lidar_scan(int32_t device, const uint8_t* map01, int32_t rows, int32_t cols, const double* poses3,
+                         int32_t n_poses, double start, double stop, double max_dist, int32_t n_rays, double* hits_xy);
+
+/* raycast<unsigned char> (slam/raycast.cpp:53-98), batched: n rays (x, y, theta). */
+int slam_raycast_u8(int32_t device, const uint8_t* map, int32_t rows, int32_t cols, const double* poses3, int64_t n,
+                    double max_distance_squared, double step_size, double* hits_xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_HIP_H */

@@ -1,0 +1,328 @@
+// detmath.h — deterministic FP64 elementary functions shared by host and gfx950 code.
+//
+// Why this exists: the reference filter calls glibc cos/sin/exp/log/fmod
+// (slam/raycast.cpp:147-148, slam/mcl.cpp:60-61,73,75, slam/util.cpp:11,47).  glibc and the ROCm
+// device libm differ in the last bit, and a 1-ulp change of cos/sin can move a ray sample across a
+// cell edge.  Every function here is built ONLY from IEEE-754 correctly rounded operations
+// (+ - * / sqrt fma) in a fixed order, so the same source gives the same bits on x86 (g++,
+// -ffp-contract=off) and on gfx950 (hipcc, -ffp-contract=off).  Accuracy is < 1 ulp
+// (tests/test_detmath.py measures it against 80-bit long double).
+//
+// Algorithms: the classic argument-reduction + minimax-polynomial schemes published with Sun's
+// fdlibm (coefficients are the published fdlibm constants, written here as bit patterns), in the
+// branch-light arrangement also used by musl/FreeBSD.  No code is taken from the reference repo.
+//
+// All translation units that include this header MUST be compiled with -ffp-contract=off.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DM_HD __host__ __device__ static inline
+#else
+#define DM_HD static inline
+#endif
+
+DM_HD uint64_t dm_bits(double x) { return __builtin_bit_cast(uint64_t, x); }
+DM_HD double dm_from_bits(uint64_t b) { return __builtin_bit_cast(double, b); }
+DM_HD double dm_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+DM_HD double dm_sqrt(double x) { return __builtin_sqrt(x); }  // IEEE correctly rounded on both sides
+DM_HD double dm_fabs(double x) { return __builtin_fabs(x); }
+DM_HD uint32_t dm_hi(double x) { return (uint32_t)(dm_bits(x) >> 32); }
+
+// ---------------------------------------------------------------------------------------------
+// x * 2^n, exact except at the subnormal edge (same operation sequence on every platform).
+DM_HD double dm_scalbn(double x, int n)
+{
+    double y = x;
+    if (n > 1023)
+    {
+        y *= dm_from_bits(0x7FE0000000000000ull);  // 2^1023
+        n -= 1023;
+        if (n > 1023)
+        {
+            y *= dm_from_bits(0x7FE0000000000000ull);
+            n -= 1023;
+            if (n > 1023) n = 1023;
+        }
+    }
+    else if (n < -1022)
+    {
+        y *= dm_from_bits(0x0360000000000000ull);  // 2^-1022 * 2^53 = 2^-969
+        n += 1022 - 53;
+        if (n < -1022)
+        {
+            y *= dm_from_bits(0x0360000000000000ull);
+            n += 1022 - 53;
+            if (n < -1022) n = -1022;
+        }
+    }
+    return y * dm_from_bits((uint64_t)(0x3ff + n) << 52);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fmod(x, y) for y > 0.  IEEE fmod is exact, so this agrees bit-for-bit with glibc's fmod
+// (slam/util.cpp:47 uses it with y = 2*pi).  Each subtraction below satisfies t <= r < 2t and is
+// therefore exact (Sterbenz).
+DM_HD double dm_fmod_pos(double x, double y)
+{
+    double r = dm_fabs(x);
+    if (!(r >= y)) return x;  // also returns NaN unchanged
+    if (dm_hi(r) >= 0x7ff00000u) return x - x;  // inf -> NaN
+    const int ey = (int)((dm_bits(y) >> 52) & 0x7ff);
+    while (r >= y)
+    {
+        const int er = (int)((dm_bits(r) >> 52) & 0x7ff);
+        double t = dm_scalbn(y, er - ey);
+        if (t > r) t *= 0.5;
+        r -= t;
+    }
+    return (dm_bits(x) >> 63) ? -r : r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Argument reduction by pi/2 (three-stage Cody-Waite, pi/2 carried to 33+33+33+53 bits).
+// Returns n (quadrant count) and y0 + y1 = x - n*pi/2.
+DM_HD int dm_rem_pio2(double x, double* y0, double* y1)
+{
+    const double invpio2 = dm_from_bits(0x3FE45F306DC9C883ull);  // 6.36619772367581382433e-01
+    const double pio2_1 = dm_from_bits(0x3FF921FB54400000ull);   // first 33 bits of pi/2
+    const double pio2_1t = dm_from_bits(0x3DD0B4611A626331ull);  // pi/2 - pio2_1
+    const double pio2_2 = dm_from_bits(0x3DD0B4611A600000ull);   // second 33 bits
+    const double pio2_2t = dm_from_bits(0x3BA3198A2E037073ull);  // pi/2 - (pio2_1+pio2_2)
+    const double pio2_3 = dm_from_bits(0x3BA3198A2E000000ull);   // third 33 bits
+    const double pio2_3t = dm_from_bits(0x397B839A252049C1ull);  // pi/2 - (pio2_1+pio2_2+pio2_3)
+
+    const uint32_t ix = dm_hi(x) & 0x7fffffffu;
+    if (ix <= 0x3fe921fbu)
+    {  // |x| <= pi/4
+        *y0 = x;
+        *y1 = 0.0;
+        return 0;
+    }
+    double t = dm_fabs(x);
+    if (ix >= 0x41300000u)
+    {
+        // |x| >= 2^20: outside the range the filter produces (normalize_angle keeps headings in
+        // (-2pi, pi]).  Deterministic but reduced-accuracy fallback: exact fmod by the double 2*pi.
+        if (ix >= 0x7ff00000u)
+        {
+            *y0 = x - x;
+            *y1 = 0.0;
+            return 0;
+        }
+        t = dm_fmod_pos(t, dm_from_bits(0x401921FB54442D18ull));
+    }
+    const int n = (int)(t * invpio2 + 0.5);
+    const double fn = (double)n;
+    double r = t - fn * pio2_1;  // fn*pio2_1 is exact (<= 21 + 33 bits)
+    double w = fn * pio2_1t;
+    const int j = (int)((dm_bits(t) >> 52) & 0x7ff);
+    double a = r - w;
+    int i = j - (int)((dm_bits(a) >> 52) & 0x7ff);
+    if (i > 16)
+    {  // 2nd stage, good to 118 bits
+        double t2 = r;
+        w = fn * pio2_2;
+        r = t2 - w;
+        w = fn * pio2_2t - ((t2 - r) - w);
+        a = r - w;
+        i = j - (int)((dm_bits(a) >> 52) & 0x7ff);
+        if (i > 49)
+        {  // 3rd stage, 151 bits
+            t2 = r;
+            w = fn * pio2_3;
+            r = t2 - w;
+            w = fn * pio2_3t - ((t2 - r) - w);
+            a = r - w;
+        }
+    }
+    const double b = (r - a) - w;
+    if (dm_bits(x) >> 63)
+    {
+        *y0 = -a;
+        *y1 = -b;
+        return -n;
+    }
+    *y0 = a;
+    *y1 = b;
+    return n;
+}
+
+// sin on [-pi/4, pi/4] of x + y (y = tail of the reduced argument).
+DM_HD double dm_ksin(double x, double y)
+{
+    const double S1 = dm_from_bits(0xBFC5555555555549ull);  // -1.66666666666666324348e-01
+    const double S2 = dm_from_bits(0x3F8111111110F8A6ull);  //  8.33333333332248946124e-03
+    const double S3 = dm_from_bits(0xBF2A01A019C161D5ull);  // -1.98412698298579493134e-04
+    const double S4 = dm_from_bits(0x3EC71DE357B1FE7Dull);  //  2.75573137070700676789e-06
+    const double S5 = dm_from_bits(0xBE5AE5E68A2B9CEBull);  // -2.50507602534068634195e-08
+    const double S6 = dm_from_bits(0x3DE5D93A5ACFD57Cull);  //  1.58969099521155010221e-10
+    const double z = x * x;
+    const double w = z * z;
+    const double r = dm_fma(z, dm_fma(z, S4, S3), S2) + (z * w) * dm_fma(z, S6, S5);
+    const double v = z * x;
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+
+// cos on [-pi/4, pi/4] of x + y.
+DM_HD double dm_kcos(double x, double y)
+{
+    const double C1 = dm_from_bits(0x3FA555555555554Cull);  //  4.16666666666666019037e-02
+    const double C2 = dm_from_bits(0xBF56C16C16C15177ull);  // -1.38888888888741095749e-03
+    const double C3 = dm_from_bits(0x3EFA01A019CB1590ull);  //  2.48015872894767294178e-05
+    const double C4 = dm_from_bits(0xBE927E4F809C52ADull);  // -2.75573143513906633035e-07
+    const double C5 = dm_from_bits(0x3E21EE9EBDB4B1C4ull);  //  2.08757232129817482790e-09
+    const double C6 = dm_from_bits(0xBDA8FAE9BE8838D4ull);  // -1.13596475577881948265e-11
+    const double z = x * x;
+    const double w = z * z;
+    const double r = z * dm_fma(z, dm_fma(z, C3, C2), C1) + (w * w) * dm_fma(z, dm_fma(z, C6, C5), C4);
+    const double hz = 0.5 * z;
+    const double q = 1.0 - hz;
+    return q + (((1.0 - q) - hz) + (z * r - x * y));
+}
+
+DM_HD void dm_sincos(double x, double* s, double* c)
+{
+    double y0, y1;
+    const int n = dm_rem_pio2(x, &y0, &y1);
+    const double sn = dm_ksin(y0, y1);
+    const double cs = dm_kcos(y0, y1);
+    switch (n & 3)
+    {
+        case 0:
+            *s = sn;
+            *c = cs;
+            break;
+        case 1:
+            *s = cs;
+            *c = -sn;
+            break;
+        case 2:
+            *s = -sn;
+            *c = -cs;
+            break;
+        default:
+            *s = -cs;
+            *c = sn;
+            break;
+    }
+}
+
+DM_HD double dm_sin(double x)
+{
+    double s, c;
+    dm_sincos(x, &s, &c);
+    return s;
+}
+
+DM_HD double dm_cos(double x)
+{
+    double s, c;
+    dm_sincos(x, &s, &c);
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Natural logarithm.  x = 2^k (1+f), sqrt(2)/2 < 1+f < sqrt(2); log(1+f) through s = f/(2+f).
+DM_HD double dm_log(double x)
+{
+    const double ln2_hi = dm_from_bits(0x3FE62E42FEE00000ull);  // 6.93147180369123816490e-01
+    const double ln2_lo = dm_from_bits(0x3DEA39EF35793C76ull);  // 1.90821492927058770002e-10
+    const double Lg1 = dm_from_bits(0x3FE5555555555593ull);     // 6.666666666666735130e-01
+    const double Lg2 = dm_from_bits(0x3FD999999997FA04ull);     // 3.999999999940941908e-01
+    const double Lg3 = dm_from_bits(0x3FD2492494229359ull);     // 2.857142874366239149e-01
+    const double Lg4 = dm_from_bits(0x3FCC71C51D8E78AFull);     // 2.222219843214978396e-01
+    const double Lg5 = dm_from_bits(0x3FC7466496CB03DEull);     // 1.818357216161805012e-01
+    const double Lg6 = dm_from_bits(0x3FC39A09D078C69Full);     // 1.531383769920937332e-01
+    const double Lg7 = dm_from_bits(0x3FC2F112DF3E5244ull);     // 1.479819860511658591e-01
+
+    uint64_t u = dm_bits(x);
+    uint32_t hx = (uint32_t)(u >> 32);
+    int k = 0;
+    if (hx < 0x00100000u || (hx >> 31))
+    {
+        if ((u << 1) == 0) return -1.0 / (x * x);  // log(+-0) = -inf
+        if (hx >> 31) return (x - x) / 0.0;        // log(-#) = NaN
+        k -= 54;                                   // subnormal: scale up
+        x *= dm_from_bits(0x4350000000000000ull);  // 2^54
+        u = dm_bits(x);
+        hx = (uint32_t)(u >> 32);
+    }
+    else if (hx >= 0x7ff00000u)
+    {
+        return x;
+    }
+    else if (hx == 0x3ff00000u && (u << 32) == 0)
+    {
+        return 0.0;
+    }
+    // reduce x into [sqrt(2)/2, sqrt(2))
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    k += (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    u = ((uint64_t)hx << 32) | (u & 0xffffffffull);
+    x = dm_from_bits(u);
+
+    const double f = x - 1.0;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * dm_fma(w, dm_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * dm_fma(w, dm_fma(w, dm_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double dk = (double)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exp(x): x = k ln2 + r, |r| <= 0.5 ln2; exp(r) through the rational form 1 + 2r/(2-c(r)).
+DM_HD double dm_exp(double x)
+{
+    const double ln2hi = dm_from_bits(0x3FE62E42FEE00000ull);
+    const double ln2lo = dm_from_bits(0x3DEA39EF35793C76ull);
+    const double invln2 = dm_from_bits(0x3FF71547652B82FEull);  // 1.44269504088896338700e+00
+    const double P1 = dm_from_bits(0x3FC555555555553Eull);      //  1.66666666666666019037e-01
+    const double P2 = dm_from_bits(0xBF66C16C16BEBD93ull);      // -2.77777777770155933842e-03
+    const double P3 = dm_from_bits(0x3F11566AAF25DE2Cull);      //  6.61375632143793436117e-05
+    const double P4 = dm_from_bits(0xBEBBBD41C5D26BF1ull);      // -1.65339022054652515390e-06
+    const double P5 = dm_from_bits(0x3E66376972BEA4D0ull);      //  4.13813679705723846039e-08
+
+    uint32_t hx = dm_hi(x);
+    const int sign = (int)(hx >> 31);
+    hx &= 0x7fffffffu;
+    if (hx >= 0x4086232bu)
+    {  // |x| >= 708.39 or NaN
+        if (x != x) return x;
+        if (x > 709.782712893383973096) return x * dm_from_bits(0x7FE0000000000000ull);  // overflow
+        if (x < -745.13321910194110842) return 0.0;                                      // underflow
+    }
+    double hi, lo;
+    int k;
+    if (hx > 0x3fd62e42u)
+    {  // |x| > 0.5 ln2
+        if (hx >= 0x3ff0a2b2u)
+            k = (int)(invln2 * x + (sign ? -0.5 : 0.5));
+        else
+            k = 1 - sign - sign;
+        hi = x - (double)k * ln2hi;  // k*ln2hi is exact
+        lo = (double)k * ln2lo;
+        x = hi - lo;
+    }
+    else if (hx > 0x3e300000u)
+    {  // |x| > 2^-28
+        k = 0;
+        hi = x;
+        lo = 0.0;
+    }
+    else
+    {
+        return 1.0 + x;
+    }
+    const double xx = x * x;
+    const double c = x - xx * dm_fma(xx, dm_fma(xx, dm_fma(xx, dm_fma(xx, P5, P4), P3), P2), P1);
+    const double y = 1.0 + (x * c / (2.0 - c) - lo + hi);
+    if (k == 0) return y;
+    return dm_scalbn(y, k);
+}

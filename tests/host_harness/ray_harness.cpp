@@ -1,0 +1,82 @@
+// ray_harness.cpp — TEST-ONLY host build of the device ray functions in slam_amd/csrc/ray.h.
+// Lets the CPU test-suite check the exact-jump / clearance logic of ray_fast_L against the
+// literal walk without a GPU.  Not shipped, not reachable from libslam_hip.so.
+#include <cstdint>
+#include <cstring>
+
+#include "../../slam_amd/csrc/clearance.h"
+#include "../../slam_amd/csrc/ray.h"
+
+#define HH_API extern "C" __attribute__((visibility("default")))
+
+HH_API void hh_build_clearance(const uint8_t* map, int rows, int cols, uint8_t* E)
+{
+    slam_build_clearance(map, rows, cols, E);
+}
+
+// returns number of rays whose (hx, hy, hcell) differ bitwise between ray_fast_L and ray_walk.
+HH_API long hh_rays_compare(const uint8_t* map, const uint8_t* E, int rows, int cols, long n, const double* sx,
+                            const double* sy, const double* theta, double zmax, long* first_bad,
+                            unsigned long long* reads_fast, unsigned long long* reads_walk, double* out_hits)
+{
+    long bad = 0;
+    *first_bad = -1;
+    *reads_fast = 0;
+    *reads_walk = 0;
+    const double zmax2 = zmax * zmax;
+    int k_safe = (int)__builtin_floor(zmax) - 1;
+    if (k_safe < 0) k_safe = 0;
+    const int max_iter = (int)__builtin_ceil(zmax) + 8;
+    for (long r = 0; r < n; ++r)
+    {
+        double s, c;
+        dm_sincos(theta[r], &s, &c);
+        slam_ray_result a, b;
+        slam_ray_stats st = {0, 0, 0};
+        unsigned reads = 0;
+        ray_walk<false, true>(const_cast<uint8_t*>(map), rows, cols, sx[r], sy[r], c, s, zmax2, zmax2, nullptr, nullptr,
+                              max_iter, &a, &st);
+        ray_fast_L(E, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b, &reads);
+        *reads_fast += reads;
+        *reads_walk += st.cells_read;
+        if (out_hits)
+        {
+            out_hits[2 * r] = a.hx;
+            out_hits[2 * r + 1] = a.hy;
+        }
+        if (std::memcmp(&a.hx, &b.hx, 8) || std::memcmp(&a.hy, &b.hy, 8) || a.hcell != b.hcell)
+        {
+            if (!bad) *first_bad = r;
+            ++bad;
+        }
+    }
+    return bad;
+}
+
+// Checks slam_advance against plain repeated addition: walks `total` steps in jumps taken from
+// jumps[] (cyclic) and compares every landing position bitwise.  Returns mismatches.
+HH_API long hh_advance_check(double x0, double y0, double dx, double dy, int total, const int* jumps, int njumps,
+                             long* jumped_steps)
+{
+    slam_axis X = {x0, 0.0, 0, 0}, Y = {y0, 0.0, 0, 0};
+    double x = x0, y = y0;
+    long bad = 0;
+    int k = 0, q = 0;
+    *jumped_steps = 0;
+    while (k < total)
+    {
+        int m = jumps[q++ % njumps];
+        if (m > total - k) m = total - k;
+        const int rem_before = X.rem < Y.rem ? X.rem : Y.rem;
+        if (rem_before > 1) *jumped_steps += (m < rem_before ? m : rem_before);
+        slam_advance(&X, &Y, dx, dy, m);
+        for (int t = 0; t < m; ++t)
+        {
+            x += dx;
+            y += dy;
+        }
+        k += m;
+        if (std::memcmp(&x, &X.v, 8) || std::memcmp(&y, &Y.v, 8)) ++bad;
+    }
+    return bad;
+}
