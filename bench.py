@@ -1,0 +1,230 @@
+"""bench.py — particle-filter step throughput on MI355X (BASELINE.json metric).
+
+One "step" = MCL::predict + MCL::update (weights from raycast + beam likelihood, running sum,
+multinomial selection, sort/gather) over the resident particle set, as in the reference's timed
+loop (benchmark/mcl.cpp:58-64: the same scan is re-applied every iteration).
+
+Workload at N = 1: BASELINE.json configs[1] — localization on assets/floor_plan.png (1297 x 599),
+100k particles x 360 beams, max range 500, sigma 5, scanner offset {0,30,0}.  N > 1 is weak scaling:
+100k particles per GPU, one process per GPU, global resampling through one RCCL all-gather per step.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ODOM = [2.5, 0.02, 0.02]            # benchmark/mcl.cpp:60
+ALPHAS = [5e-4, 5e-4, 1e-2, 1e-2]   # benchmark/mcl.cpp:61
+OFFSET = [0.0, 30.0, 0.0]           # apps/grid_slam.cpp:99
+STDDEV, MAX_DIST = 5.0, 500.0       # apps/grid_slam.cpp:88-89
+TRUE_POSE = [520.0, 280.0, 0.4]
+SEED = 0x5EED0001
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def load_free_grid(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "maps.npz"))
+    sh = z[name + "_shape"]
+    return np.unpackbits(z[name + "_bits"])[: int(sh[0]) * int(sh[1])].reshape(int(sh[0]), int(sh[1]))
+
+
+def synth_scan(sa, free, device, n_beams):
+    """apps/grid_slam.cpp:144-166 with the device FakeLidar: sensor pose -> hits -> (angle, dist)."""
+    from slam_amd import capi
+
+    lib = capi.load_library()
+    sensor = sa.MCL.sensor_position(sa.Pose(*TRUE_POSE), sa.Pose(*OFFSET))
+    pose = np.array([[sensor.x, sensor.y, sensor.theta]])
+    hits = np.empty((n_beams, 2))
+    m01 = np.ascontiguousarray(free, dtype=np.uint8)
+    capi.check(lib.slam_fake_lidar_scan(device, capi.ptr(m01), m01.shape[0], m01.shape[1], capi.ptr(pose), 1, 0.0,
+                                        2 * np.pi, MAX_DIST, n_beams, capi.ptr(hits)))
+    step = 2 * np.pi / n_beams
+    ang = np.arange(n_beams) * step - np.pi
+    d = np.sqrt((hits[:, 1] - sensor.y) ** 2 + (hits[:, 0] - sensor.x) ** 2)
+    dist = np.where(hits[:, 0] != -1, d, MAX_DIST)
+    return ang, dist
+
+
+def cpu_baseline(free, ang, dist, n_beams, budget_s=12.0):
+    """The CPU oracle (port of the reference's update loop, threaded like slam/mcl.cpp:120-137) timed on
+    a bounded sample of the same workload.  Checker code, called from here only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc
+
+    cores = min(16, len(os.sched_getaffinity(0)))
+    g = (free * 255).astype(np.uint8)
+    rng = np.random.default_rng(0)
+
+    def run(n):
+        x = TRUE_POSE[0] + 25 * rng.standard_normal(n)
+        y = TRUE_POSE[1] + 25 * rng.standard_normal(n)
+        th = TRUE_POSE[2] + 0.2 * rng.standard_normal(n)
+        z = orc.philox_normals(SEED, 0, 0, n)
+        t0 = time.perf_counter()
+        x, y, th = orc.predict(x, y, th, ODOM, ALPHAS, z)
+        w, _ = orc.update_weights(x, y, th, g, ang, dist, STDDEV, MAX_DIST, OFFSET, n_threads=cores, fast=True)
+        idx, _, _ = orc.resample(w, orc.philox_uniforms(SEED, 0, 0, n), orc.ORDER_REFERENCE)
+        orc.sort_order(w[idx], 1)
+        return time.perf_counter() - t0
+
+    n0 = 64 * cores
+    t = run(n0)
+    n = int(max(n0, min(200000, n0 * budget_s / max(t, 1e-3))))
+    t = run(n)
+    return {"value": n * n_beams / t, "unit": "particle-beams/s", "cores": cores, "kind": "port",
+            "sample": f"{n} particles x {n_beams} beams of the same workload, one full step (predict+update), "
+                      f"{t:.2f} s, oracle built with the reference's flags (-Ofast), {cores} threads in the "
+                      f"reference's slicing"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles", type=int, default=100_000, help="particles per GPU")
+    ap.add_argument("--beams", type=int, default=360)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import slam_amd as sa
+    from slam_amd import capi
+    from slam_amd.dist import HipShard, ShardedFilter
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    free = load_free_grid("floor_plan")
+    grid = (free * 255).astype(np.uint8)
+    rows, cols = grid.shape
+    n_loc, B = args.particles, args.beams
+    ang, dscan = synth_scan(sa, free, local_rank, B)
+
+    if world == 1:
+        f = sa.Filter(n_loc, rows, cols, device=local_rank, seed=SEED, stream=stream, async_launch=True)
+        f.set_map(grid)
+        step_predict = lambda: f.predict(ODOM, ALPHAS)
+        step_update = lambda: f.update(ang, dscan, STDDEV, MAX_DIST, OFFSET)
+    else:
+        shard = HipShard(n_loc, rows, cols, rank, world, local_rank, SEED, stream=stream, async_launch=True)
+        shard.set_map(grid)
+        sf = ShardedFilter(shard, world=world)
+        f = shard.f
+        step_predict = lambda: sf.predict(ODOM, ALPHAS)
+        step_update = lambda: sf.update(ang, dscan, STDDEV, MAX_DIST, OFFSET)
+    f.seed_gaussian(TRUE_POSE, [25.0, 25.0, 0.2])  # Gaussian cloud around the true pose
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def measure_sbar():
+        """Mean cells the reference's walk reads per ray for the CURRENT poses (cell-by-cell kernel)."""
+        x, y, th = f.poses()
+        wk = sa.Filter(n_loc, rows, cols, device=local_rank, raycaster=capi.RAYCAST_WALK, sort=capi.SORT_NONE)
+        wk.set_map(grid)
+        wk.set_poses(x, y, th)
+        wk.update_weights(ang, dscan, STDDEV, MAX_DIST, OFFSET)
+        s = wk.stats()["cells_read"] / float(n_loc * B)
+        wk.close()
+        return s
+
+    for _ in range(args.warmup):
+        step_predict()
+        step_update()
+    torch.cuda.synchronize()
+    sbar0 = measure_sbar() if rank == 0 else 0.0
+    f.profile(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_predict()
+        step_update()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kms = f.kernel_ms()
+    f.profile(False)
+
+    if rank == 0:
+        sbar1 = measure_sbar()
+        sbar = 0.5 * (sbar0 + sbar1)
+        ms_step = elapsed / args.steps * 1e3
+        total_pb = float(world) * n_loc * B
+        w_ms, w_n = kms["weights"]
+        k_avg_ms = w_ms / max(w_n, 1)
+        # per particle-beam S_bar x 1 B (cells the reference reads) + 40/B B (pose in, weight out)
+        alg_bytes = n_loc * B * sbar + 40.0 * n_loc + 16.0 * B
+        achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_weights_kernel.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "particle-beam raycasts+likelihoods/sec",
+            "value": total_pb / (ms_step * 1e-3),
+            "unit": "particle-beams/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: MCL localization, floor_plan 1297x599, {n_loc} particles x {B} beams per GPU, "
+                            f"max_dist {MAX_DIST:g}, sigma {STDDEV:g}, full step = predict + update (weights, running sum, "
+                            f"multinomial select, {'sort, ' if world == 1 else ''}gather)",
+                "particles_per_gpu": n_loc, "beams": B, "map": "floor_plan", "noise": "philox4x32-10",
+                "resampling": "multinomial (reference rule)" + ("" if world == 1 else ", global over all ranks via one all-gather"),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_weights_L<0> (raycast + beam likelihood)", "kernel_avg_ms": k_avg_ms,
+                "algorithmic_bytes_per_launch": alg_bytes, "cells_per_ray_reference_walk": sbar,
+                "kernel_particle_beams_per_s": n_loc * B / (k_avg_ms * 1e-3),
+            },
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kms.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(free, ang, dscan, B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

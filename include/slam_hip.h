@@ -63,6 +63,10 @@ typedef struct slam_mcl_params
     int64_t global_first;  /* index of this shard's first particle in the whole filter */
     int64_t global_n;      /* particles in the whole filter (0 = n_particles) */
     void* stream;          /* hipStream_t to launch on (NULL = the null stream) */
+    int32_t async_launch;  /* 0: predict/update* return after the stream has drained (default).
+                              1: they return after enqueueing; the caller orders later work on
+                              `stream` or calls slam_mcl_synchronize */
+    int32_t reserved;
 } slam_mcl_params;
 
 const char* slam_last_error(void);
@@ -81,7 +85,7 @@ int slam_mcl_set_map_u8(slam_mcl* h, const uint8_t* map, int32_t rows, int32_t c
 /* Particle seeding / direct state access (no reference counterpart beyond reset_particles). */
 int slam_mcl_set_poses(slam_mcl* h, const double* x, const double* y, const double* theta, int64_t first, int64_t count);
 int slam_mcl_seed_gaussian(slam_mcl* h, const double mean[3], const double sigma[3]);
-int slam_mcl_seed_uniform_free(slam_mcl* h);
+int slam_mcl_set_weights(slam_mcl* h, const double* w, int64_t first, int64_t count);
 int slam_mcl_set_maps_u8(slam_mcl* h, const uint8_t* maps, int64_t first, int64_t count); /* SLAM mode */
 
 /* Noise injection (SLAM_NOISE_INJECTED): unit normals z[3*n_particles] consumed by the next
@@ -125,29 +129,29 @@ int slam_mcl_get_stats(slam_mcl* h, int64_t out[3]);
 int slam_mcl_profile(slam_mcl* h, int32_t enable);
 int slam_mcl_get_kernel_ms(slam_mcl* h, double ms[5], int64_t launches[5], int32_t reset);
 
-/* Device pointers of the resident state (for RCCL collectives issued by the caller). */
+/* Device pointers of the resident state (for RCCL collectives issued by the caller).  The state
+ * of a shard is one packed buffer [x | y | theta | weight], n_particles doubles each; the pointer
+ * changes after every resample (double buffering), so query it again after each update. */
 typedef struct slam_mcl_device_state
 {
-    double* x_dev;
-    double* y_dev;
-    double* theta_dev;
-    double* weight_dev;
-    double* prefix_dev;      /* n_particles inclusive running sums */
-    double* chunk_totals_dev;/* ceil(n/64) totals of the level-0 chunks */
+    double* state_dev;       /* 4 * n_particles doubles */
+    double* prefix_dev;      /* global_n inclusive running sums of the last resample */
     int64_t n_particles;
+    int64_t global_n;
 } slam_mcl_device_state;
 int slam_mcl_device_state_get(slam_mcl* h, slam_mcl_device_state* out);
 
-/* Sharded resampling, used by one-process-per-GPU drivers:
- *  1. slam_mcl_shard_scan: level-0 chunk scans of the local weights -> chunk totals (device).
- *  2. caller all-gathers chunk totals, poses and weights of all shards (RCCL).
- *  3. slam_mcl_shard_select: builds the global running sum in the canonical blocked order from
- *     the gathered chunk totals + gathered weights, draws this shard's slots, and gathers the
- *     selected particles from the gathered state into this shard.  All *_dev arrays have
- *     global_n entries (chunk totals: ceil(global_n/64)). */
-int slam_mcl_shard_scan(slam_mcl* h);
-int slam_mcl_shard_select(slam_mcl* h, const double* all_x_dev, const double* all_y_dev, const double* all_theta_dev,
-                          const double* all_w_dev);
+/* Sharded resampling for one-process-per-GPU drivers.  Every shard holds
+ * n_particles = global_n / n_shards particles (a multiple of 64).  After update_weights the caller
+ * all-gathers the packed state buffers of all shards, in shard order, into gathered_state_dev
+ * ([n_shards][4][n_particles] doubles, i.e. the plain concatenation all-gather produces).  This call
+ * then builds the running sum of ALL weights in the canonical blocked order, draws this shard's
+ * output slots (global slot index = global_first + k) with the rule of slam/mcl.cpp:179-203, and
+ * copies the selected particles out of the gathered buffer.  The result is bit-identical to a single
+ * handle with n_particles = global_n and SLAM_SORT_NONE, for any number of shards.
+ * Requires localization mode, SLAM_SORT_NONE, SLAM_PREFIX_BLOCKED. */
+int slam_mcl_shard_resample(slam_mcl* h, const double* gathered_state_dev, int32_t n_shards);
+int slam_mcl_synchronize(slam_mcl* h);
 
 /* FakeLidar::scan (slam/fake_lidar.cpp:15-33) + raycast<int> (slam/raycast.cpp:100-141), batched
  * on the device: n_poses sensor poses x n_rays rays on a CV_32S-style map given as uint8 (0 = wall).

@@ -1,0 +1,422 @@
+// kernels.h — gfx950 kernels of the particle-filter step (included by slam_hip.hip only).
+//
+// Kernel groups (SURVEY.md §2 "what the build writes instead"):
+//   K1  k_predict            slam/motion.cpp:9-32 + slam/util.cpp:45-51, one thread per particle
+//   K2a k_weights_L          localization mode: one wavefront per particle, lanes over beams
+//   K2b k_weights_S          SLAM mode: slam/raycast.cpp:143-223 with map updates, beams in order
+//   K3  k_scan_chunks / k_downsweep / k_prefix_seq / k_select / k_gather   slam/mcl.cpp:157-203
+//   K4  sort keys + gather (rocPRIM radix sort drives the permutation)     slam/mcl.cpp:232-239
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "detmath.h"
+#include "noise.h"
+#include "ray.h"
+
+namespace slamk
+{
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct PredictArgs
+{
+    int64_t n;
+    double *x, *y, *th;
+    double r1, t, r2;
+    double s1, st, s2;  // the three sigmas of slam/motion.cpp:15-25 (uniform over particles)
+    uint64_t seed, step, global_first;
+    const double* injected;  // 3*n unit normals or nullptr
+};
+
+__global__ void __launch_bounds__(256) k_predict(PredictArgs a)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    double z[3];
+    if (a.injected)
+    {
+        z[0] = a.injected[3 * p];
+        z[1] = a.injected[3 * p + 1];
+        z[2] = a.injected[3 * p + 2];
+    }
+    else
+        slam_motion_normals(a.seed, a.step, a.global_first + (uint64_t)p, z);
+    const double rotation_1 = a.r1 - z[0] * a.s1;
+    const double translation = a.t - z[1] * a.st;
+    const double rotation_2 = a.r2 - z[2] * a.s2;
+    const double th = a.th[p];
+    double s, c;
+    dm_sincos(th + rotation_1, &s, &c);
+    const double nx = a.x[p] + translation * c;
+    const double ny = a.y[p] + translation * s;
+    const double twopi = dm_from_bits(0x401921FB54442D18ull);
+    double angle = dm_fmod_pos(th + rotation_1 + rotation_2, twopi);
+    if (angle > dm_from_bits(0x400921FB54442D18ull)) angle -= twopi;
+    a.x[p] = nx;
+    a.y[p] = ny;
+    a.th[p] = angle;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WeightArgs
+{
+    int64_t n;
+    const double *x, *y, *th;
+    uint8_t* grid;         // L/FAST: clearance grid; L/WALK: raw map; S: per-particle maps
+    size_t map_stride;     // S mode: bytes between particle maps
+    int rows, cols, B;
+    const double *angles, *z2, *z;  // per beam: angle, dist^2, sqrt(dist^2)
+    double zmax2, zmax, stddev, norm;
+    double sd, stheta, srot;        // scanner displacement (slam/mcl.cpp:80-86) and rotation
+    int k_safe, max_iter;
+    double* w;
+    double* hit_xy;   // optional n*B*2
+    int32_t* hit_cell;  // optional n*B
+    unsigned long long* stats;  // optional 3 counters
+    const uint8_t* luts;        // 512 bytes: free table then occupied table
+};
+
+// K2a.  VARIANT 0: ray_fast_L on the clearance grid.  VARIANT 1: literal walk on the raw map
+// (counts cells).  One wavefront = one particle; lane l takes beams l, l+64, ...; the per-beam
+// log-likelihoods are then added in beam order (slam/mcl.cpp:69-74) so the weight has the
+// reference's rounding.
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= a.n) return;  // whole wavefront
+    const double px = a.x[p], py = a.y[p], pth = a.th[p];
+    double s0, c0;
+    dm_sincos(pth + a.stheta, &s0, &c0);
+    const double sx = px + c0 * a.sd;
+    const double sy = py + s0 * a.sd;
+    double acc = 0.0;
+    slam_ray_stats st = {0, 0, 0};
+    for (int b0 = 0; b0 < a.B; b0 += 64)
+    {
+        const int b = b0 + lane;
+        double lw = 0.0;
+        if (b < a.B)
+        {
+            const double theta = pth + a.angles[b] + a.srot;
+            double s, c;
+            dm_sincos(theta, &s, &c);
+            slam_ray_result r;
+            if (VARIANT == 0)
+                ray_fast_L(a.grid, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr);
+            else
+                ray_walk<false, true>(a.grid, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, nullptr, nullptr,
+                                      a.max_iter, &r, &st);
+            lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm);
+            if (a.hit_xy)
+            {
+                const size_t o = (size_t)p * a.B + b;
+                a.hit_xy[2 * o] = r.hx;
+                a.hit_xy[2 * o + 1] = r.hy;
+                a.hit_cell[o] = r.hcell;
+            }
+        }
+        const int cnt = (a.B - b0) < 64 ? (a.B - b0) : 64;
+        for (int l = 0; l < cnt; ++l) acc += readlane_f64(lw, l);
+    }
+    if (lane == 0) a.w[p] = dm_exp(acc);
+    if (VARIANT == 1 && a.stats)
+    {
+        atomicAdd(&a.stats[0], st.cells_read);
+        atomicAdd(&a.stats[1], st.cells_written);
+        atomicAdd(&a.stats[2], st.steps);
+    }
+}
+
+// K2b, first form: one thread per particle, beams and cells strictly in the reference's order.
+__global__ void __launch_bounds__(64) k_weights_S(WeightArgs a)
+{
+    __shared__ uint8_t luts[512];
+    for (int t = threadIdx.x; t < 512; t += blockDim.x) luts[t] = a.luts[t];
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    uint8_t* map = a.grid + a.map_stride * (size_t)p;
+    const double px = a.x[p], py = a.y[p], pth = a.th[p];
+    double s0, c0;
+    dm_sincos(pth + a.stheta, &s0, &c0);
+    const double sx = px + c0 * a.sd;
+    const double sy = py + s0 * a.sd;
+    double acc = 0.0;
+    slam_ray_stats st = {0, 0, 0};
+    for (int b = 0; b < a.B; ++b)
+    {
+        const double theta = pth + a.angles[b] + a.srot;
+        double s, c;
+        dm_sincos(theta, &s, &c);
+        slam_ray_result r;
+        ray_walk<true, true>(map, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, luts, luts + 256, a.max_iter, &r, &st);
+        acc += slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm);
+        if (a.hit_xy)
+        {
+            const size_t o = (size_t)p * a.B + b;
+            a.hit_xy[2 * o] = r.hx;
+            a.hit_xy[2 * o + 1] = r.hy;
+            a.hit_cell[o] = r.hcell;
+        }
+    }
+    a.w[p] = dm_exp(acc);
+    if (a.stats)
+    {
+        atomicAdd(&a.stats[0], st.cells_read);
+        atomicAdd(&a.stats[1], st.cells_written);
+        atomicAdd(&a.stats[2], st.steps);
+    }
+}
+
+// Particle state is stored packed, [x | y | theta | weight], n doubles each.  A "gathered" buffer
+// holds the packed states of all shards back to back ([shard][4][n_loc]), which is exactly what an
+// all-gather of the per-shard buffers produces.
+struct StateView
+{
+    const double* base;
+    int64_t n_loc;  // particles per shard
+};
+__device__ __forceinline__ double sv_get(const StateView& v, int q, int64_t i)
+{
+    const int64_t r = i / v.n_loc;
+    const int64_t o = i - r * v.n_loc;
+    return v.base[(r * 4 + q) * v.n_loc + o];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3.  Canonical blocked running sum: radix-64 hierarchy of Hillis-Steele wavefront scans.
+// s[i] = inclusive scan inside the 64-chunk of i; tot[c] = last element of chunk c.
+// Input: a[i], or (a == nullptr) the weight column of a gathered state view.
+__global__ void __launch_bounds__(256) k_scan_chunks(const double* a, StateView view, int64_t n, double* s, double* tot)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t i = c * 64 + lane;
+    if (c * 64 >= n) return;
+    double v = i < n ? (a ? a[i] : sv_get(view, 3, i)) : 0.0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const double t = __shfl_up(v, d, 64);
+        if (lane >= d) v = t + v;
+    }
+    if (i < n) s[i] = v;
+    const int64_t last = (c * 64 + 63 < n - 1) ? c * 64 + 63 : n - 1;
+    if (i == last) tot[c] = v;
+}
+
+// P[j] = (inclusive running sum of all earlier chunks) + s[j]
+__global__ void __launch_bounds__(256) k_downsweep(const double* s, const double* Pnext, int64_t n, double* P)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t c = j >> 6;
+    P[j] = c ? Pnext[c - 1] + s[j] : s[j];
+}
+
+// The reference's order (slam/mcl.cpp:170-176): strictly sequential, one thread.
+__global__ void k_prefix_seq(const double* w, int64_t n, double* P)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    double acc = w[0];
+    P[0] = acc;
+    for (int64_t i = 1; i < n; ++i)
+    {
+        acc = acc + w[i];
+        P[i] = acc;
+    }
+}
+
+struct SelectArgs
+{
+    const double* P;        // running sums over n_total entries
+    int64_t n_total;
+    int64_t slot_first;     // global index of this shard's first output slot
+    int64_t n_slots;
+    const double* injected; // n_slots canonical uniforms or nullptr
+    uint64_t seed, step;
+    int resampler;
+    int32_t* idx;           // n_slots selected global indices
+};
+
+// slam/mcl.cpp:179-203: cutoff = canonical * sum; bisection in which equality returns mid.
+__global__ void __launch_bounds__(256) k_select(SelectArgs a)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_slots) return;
+    const double sum = a.P[a.n_total - 1];
+    double cutoff;
+    if (a.resampler == 0)
+    {
+        const double canon = a.injected ? a.injected[k] : slam_resample_uniform(a.seed, a.step, (uint64_t)(a.slot_first + k));
+        cutoff = canon * sum;
+    }
+    else
+    {
+        const double canon = a.injected ? a.injected[0] : slam_resample_uniform(a.seed, a.step, 0);
+        cutoff = ((double)(a.slot_first + k) + canon) * (sum / (double)a.n_total);
+    }
+    int i = 0;
+    int j = (int)a.n_total - 1;
+    while (i < j)
+    {
+        const int mid = i + (j - i) / 2;
+        const double c = a.P[mid];
+        if (c == cutoff)
+        {
+            i = mid;
+            j = mid;
+        }
+        else if (c < cutoff)
+            i = mid + 1;
+        else
+            j = mid;
+    }
+    a.idx[k] = i;
+}
+
+// sort keys: weight of the particle selected for slot k; payload: k
+__global__ void __launch_bounds__(256) k_sort_keys(StateView view, const int32_t* idx, int64_t n, double* keys, int32_t* slots)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    keys[k] = sv_get(view, 3, idx[k]);
+    slots[k] = (int32_t)k;
+}
+
+// src[p] = idx[perm[p]] (perm == nullptr: identity); new state p = old state src[p]
+__global__ void __launch_bounds__(256) k_gather(StateView view, const int32_t* idx, const int32_t* perm, int64_t n,
+                                                double* dst /* packed [4][n] */, int32_t* src)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t s = idx[perm ? perm[p] : p];
+    const int64_t r = s / view.n_loc;
+    const int64_t o = s - r * view.n_loc;
+    const double* from = view.base + r * 4 * view.n_loc + o;
+    dst[p] = from[0];
+    dst[n + p] = from[view.n_loc];
+    dst[2 * n + p] = from[2 * view.n_loc];
+    dst[3 * n + p] = from[3 * view.n_loc];
+    src[p] = s;
+}
+
+// slam/mcl.cpp:147-155: deep copy of each selected particle's map.  grid = (chunks, particles).
+__global__ void __launch_bounds__(256) k_clone_maps(const uint8_t* maps, uint8_t* maps2, const int32_t* src,
+                                                    size_t stride)
+{
+    const size_t p = blockIdx.y;
+    const uint4* from = reinterpret_cast<const uint4*>(maps + stride * (size_t)src[p]);
+    uint4* to = reinterpret_cast<uint4*>(maps2 + stride * p);
+    const size_t n16 = stride / 16;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n16; t += (size_t)gridDim.x * blockDim.x)
+        to[t] = from[t];
+}
+
+__global__ void __launch_bounds__(256) k_fill_poses(int64_t n, double* x, double* y, double* th, double* w, double vx,
+                                                    double vy, double vth, double vw)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    x[p] = vx;
+    y[p] = vy;
+    th[p] = vth;
+    w[p] = vw;
+}
+
+// Gaussian seeding around a pose (localization mode; no reference counterpart).
+__global__ void __launch_bounds__(256) k_seed_gaussian(int64_t n, double* x, double* y, double* th, double* w, double mx,
+                                                       double my, double mth, double sxy_x, double sxy_y, double sth,
+                                                       uint64_t seed, uint64_t global_first, double vw)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double a, b, c, d;
+    slam_normal_pair(seed, SLAM_STREAM_SEED, 0, global_first + (uint64_t)p, 0, &a, &b);
+    slam_normal_pair(seed, SLAM_STREAM_SEED, 0, global_first + (uint64_t)p, 1, &c, &d);
+    x[p] = mx + a * sxy_x;
+    y[p] = my + b * sxy_y;
+    th[p] = mth + c * sth;
+    w[p] = vw;
+}
+
+// slam/util.cpp:66-85 average_pose: per-block partial sums (fixed tree), finished on the host.
+__global__ void __launch_bounds__(256) k_pose_partials(int64_t n, const double* x, const double* y, const double* th,
+                                                       double* partial /* 4 per block */)
+{
+    __shared__ double sh[4][256];
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double vx = 0, vy = 0, vc = 0, vs = 0;
+    if (p < n)
+    {
+        vx = x[p];
+        vy = y[p];
+        dm_sincos(th[p], &vs, &vc);
+    }
+    sh[0][threadIdx.x] = vx;
+    sh[1][threadIdx.x] = vy;
+    sh[2][threadIdx.x] = vc;
+    sh[3][threadIdx.x] = vs;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1)
+    {
+        if ((int)threadIdx.x < d)
+            for (int q = 0; q < 4; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 4; ++q) partial[4 * blockIdx.x + q] = sh[q][0];
+}
+
+// Batched read-only raycasts (slam/raycast.cpp:53-141), one thread per ray.
+// KIND 1: unsigned char map, tests distance -> bounds -> (<128).  KIND 2: "int" map given as
+// uint8 0/1, tests bounds -> distance -> (==0)  (FakeLidar's raycast<int>).
+template <int KIND>
+__global__ void __launch_bounds__(256) k_raycast_ro(const uint8_t* map, int rows, int cols, int64_t n, const double* px,
+                                                    const double* py, const double* pth, double max2, double step,
+                                                    int max_iter, double* hits)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double s, c;
+    dm_sincos(pth[r], &s, &c);
+    const double dx = step * c, dy = step * s;
+    const double ox = px[r], oy = py[r];
+    double x = ox, y = oy;
+    int i, j;
+    slam_cell_of(rows, x, y, &i, &j);
+    int pi = i, pj = j;
+    double hx = -1.0, hy = -1.0;
+    for (int it = 0; it < max_iter; ++it)
+    {
+        x += dx;
+        y += dy;
+        slam_cell_of(rows, x, y, &i, &j);
+        if (i == pi && j == pj) continue;
+        const double ex = x - ox, ey = y - oy;
+        const bool far = (ex * ex + ey * ey) >= max2;
+        const bool inb = slam_in_bounds(rows, cols, i, j);
+        if (far || !inb) break;  // both orders of the two tests end the ray without a hit
+        const uint8_t v = map[(size_t)i * cols + j];
+        if (KIND == 1 ? (v < 128) : (v == 0))
+        {
+            hx = x;
+            hy = y;
+            break;
+        }
+        pi = i;
+        pj = j;
+    }
+    hits[2 * r] = hx;
+    hits[2 * r + 1] = hy;
+}
+
+}  // namespace slamk

@@ -1,0 +1,977 @@
+// slam_hip.hip — C ABI (include/slam_hip.h) over the gfx950 kernels in kernels.h.
+// Compile with hipcc --offload-arch=gfx950 -ffp-contract=off (see slam_amd/build.py).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <rocprim/rocprim.hpp>
+#include <string>
+#include <vector>
+
+#include "../../include/slam_hip.h"
+#include "clearance.h"
+#include "kernels.h"
+
+#define SLAM_API extern "C" __attribute__((visibility("default")))
+
+namespace
+{
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                       \
+    do                                                                                                     \
+    {                                                                                                      \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(SLAM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                                          ":" + std::to_string(__LINE__) + ")");                           \
+    } while (0)
+
+enum
+{
+    G_PREDICT = 0,
+    G_WEIGHTS = 1,
+    G_RESAMPLE = 2,
+    G_SORT = 3,
+    G_CLONE = 4,
+    G_COUNT = 5
+};
+
+struct TimedSpan
+{
+    int group;
+    hipEvent_t a, b;
+};
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+}  // namespace
+
+struct slam_mcl
+{
+    slam_mcl_params prm;
+    hipStream_t stream = nullptr;
+    int64_t n = 0;
+    int rows = 0, cols = 0;
+    size_t map_stride = 0;
+    // resident state (double buffered for the resample gather)
+    // packed [x | y | theta | weight], n doubles each; x/y/th/w point into `state`
+    double *state = nullptr, *state2 = nullptr;
+    double *x = nullptr, *y = nullptr, *th = nullptr, *w = nullptr;
+    int64_t n_glob = 0;  // particles of the whole filter (all shards)
+
+    void bind()
+    {
+        x = state;
+        y = state + n;
+        th = state + 2 * n;
+        w = state + 3 * n;
+    }
+    uint8_t *grid = nullptr, *clr = nullptr;     // localization: raw map + clearance grid
+    uint8_t *maps = nullptr, *maps2 = nullptr;   // SLAM: per-particle canvases
+    uint8_t* luts = nullptr;
+    bool have_map = false;
+    // scan
+    int Bcap = 0;
+    double *angles = nullptr, *z2 = nullptr, *z = nullptr;
+    std::vector<double> scan_cache;
+    int last_B = 0;
+    // noise
+    double *inj_normals = nullptr, *inj_uniforms = nullptr;
+    bool have_normals = false, have_uniforms = false;
+    uint64_t predict_step = 0, resample_step = 0;
+    // resampling
+    std::vector<int64_t> lvl_n;
+    std::vector<double*> lvl_s, lvl_P, lvl_tot;  // lvl_tot[l] = input array of level l+1
+    int32_t *idx = nullptr, *perm = nullptr, *slots = nullptr, *src = nullptr;
+    double *keys = nullptr, *keys2 = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    // diagnostics
+    bool record_hits = false;
+    double* hit_xy = nullptr;
+    int32_t* hit_cell = nullptr;
+    size_t hit_cap = 0;
+    unsigned long long* stats = nullptr;
+    double* partials = nullptr;
+    bool profile = false;
+    std::vector<TimedSpan> spans;
+    double acc_ms[G_COUNT] = {0, 0, 0, 0, 0};
+    int64_t acc_launches[G_COUNT] = {0, 0, 0, 0, 0};
+
+    struct Span
+    {
+        slam_mcl* h;
+        TimedSpan s;
+        bool on;
+        Span(slam_mcl* h_, int group) : h(h_), on(h_->profile)
+        {
+            if (!on) return;
+            s.group = group;
+            hipEventCreate(&s.a);
+            hipEventCreate(&s.b);
+            hipEventRecord(s.a, h->stream);
+        }
+        ~Span()
+        {
+            if (!on) return;
+            hipEventRecord(s.b, h->stream);
+            h->spans.push_back(s);
+        }
+    };
+};
+
+namespace
+{
+template <class T>
+int dev_alloc(T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) return SLAM_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess)
+        return fail(SLAM_ERR_NOMEM, std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) + " bytes: " +
+                                        hipGetErrorString(e));
+    return SLAM_OK;
+}
+
+int finish(slam_mcl* h)
+{
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+// The two update tables of slam/raycast.cpp:196-211, evaluated as written there (double
+// arithmetic, truncating casts; this translation unit is compiled without contraction or
+// fast-math, so the values equal a strict-IEEE build of the reference).
+void build_luts(uint8_t* t)
+{
+    const double L0 = 0.5, Locc = 0.40, Lfree = 0.60;
+    for (int c = 0; c < 256; ++c)
+    {
+        double p = static_cast<double>(static_cast<unsigned char>(c)) / 255;
+        p *= Lfree / L0;
+        p = p < 1.0 ? p : 1.0;
+        unsigned char v = static_cast<unsigned char>(p * 255);
+        t[c] = v < 1 ? 1 : v;
+        double q = static_cast<double>(static_cast<unsigned char>(c)) / 255;
+        q *= Locc / L0;
+        unsigned char u = static_cast<unsigned char>(q * 255);
+        t[256 + c] = u < 1 ? 1 : u;
+    }
+}
+
+int check_handle(slam_mcl* h)
+{
+    if (!h) return fail(SLAM_ERR_ARG, "null handle");
+    hipError_t e = hipSetDevice(h->prm.device);
+    if (e != hipSuccess) return fail(SLAM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return SLAM_OK;
+}
+
+int upload_scan(slam_mcl* h, const double* angles, const double* dists, int B)
+{
+    if (!angles || !dists || B <= 0) return fail(SLAM_ERR_ARG, "scan: null pointer or n_beams <= 0");
+    for (int b = 0; b < B; ++b)
+        if (!std::isfinite(angles[b]) || !std::isfinite(dists[b])) return fail(SLAM_ERR_ARG, "scan: non-finite entry");
+    if (B > h->Bcap)
+    {
+        hipFree(h->angles);
+        hipFree(h->z2);
+        hipFree(h->z);
+        h->Bcap = 0;
+        int rc;
+        if ((rc = dev_alloc(&h->angles, B)) || (rc = dev_alloc(&h->z2, B)) || (rc = dev_alloc(&h->z, B))) return rc;
+        h->Bcap = B;
+        h->scan_cache.clear();
+    }
+    // host copy: angle, dist^2 (slam/mcl.cpp:72 passes dist*dist), sqrt(dist^2) (slam/raycast.cpp:236,241)
+    std::vector<double> pack(3 * (size_t)B);
+    for (int b = 0; b < B; ++b)
+    {
+        pack[b] = angles[b];
+        const double d2 = dists[b] * dists[b];
+        pack[B + b] = d2;
+        pack[2 * (size_t)B + b] = std::sqrt(d2);
+    }
+    if (h->last_B == B && h->scan_cache == pack) return SLAM_OK;  // same scan re-applied (benchmark/mcl.cpp:58-64)
+    HIPCHK(hipMemcpyAsync(h->angles, pack.data(), sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->z2, pack.data() + B, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->z, pack.data() + 2 * (size_t)B, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->scan_cache.swap(pack);
+    h->last_B = B;
+    return SLAM_OK;
+}
+
+int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double off[3])
+{
+    if (!(stddev > 0) || !std::isfinite(stddev) || !(max_dist >= 0) || !std::isfinite(max_dist))
+        return fail(SLAM_ERR_ARG, "stddev must be > 0 and max_dist >= 0, both finite");
+    if (!off || !std::isfinite(off[0]) || !std::isfinite(off[1]) || !std::isfinite(off[2]))
+        return fail(SLAM_ERR_ARG, "scanner_offset: null or non-finite");
+    const bool slam_mode = h->prm.mode == SLAM_MODE_SLAM;
+    if (!slam_mode && !h->have_map) return fail(SLAM_ERR_STATE, "localization mode: call slam_mcl_set_map_u8 first");
+    if (h->record_hits)
+    {
+        const size_t need = (size_t)h->n * B;
+        if (need > h->hit_cap)
+        {
+            hipFree(h->hit_xy);
+            hipFree(h->hit_cell);
+            h->hit_cap = 0;
+            int rc;
+            if ((rc = dev_alloc(&h->hit_xy, 2 * need)) || (rc = dev_alloc(&h->hit_cell, need))) return rc;
+            h->hit_cap = need;
+        }
+    }
+    slamk::WeightArgs a;
+    a.n = h->n;
+    a.x = h->x;
+    a.y = h->y;
+    a.th = h->th;
+    a.map_stride = h->map_stride;
+    a.rows = h->rows;
+    a.cols = h->cols;
+    a.B = B;
+    a.angles = h->angles;
+    a.z2 = h->z2;
+    a.z = h->z;
+    a.zmax2 = max_dist * max_dist;      // slam/mcl.cpp:68
+    a.zmax = std::sqrt(a.zmax2);        // slam/raycast.cpp:236
+    a.stddev = stddev;
+    a.norm = 1.0 / (stddev * std::sqrt(2 * M_PI));  // slam/util.cpp:11
+    // slam/mcl.cpp:80-86 with the int-returning squared distance of slam/util.h:138-146
+    {
+        const double ddx = 0 - off[0], ddy = 0 - off[1];
+        const double sq = ddx * ddx + ddy * ddy;
+        if (!(sq < 2147483648.0)) return fail(SLAM_ERR_ARG, "scanner_offset too large");
+        a.sd = std::sqrt(static_cast<double>(static_cast<int>(sq)));
+        a.stheta = std::atan2(off[1], off[0]);
+        a.srot = off[2];
+    }
+    int ks = (int)std::floor(std::fmin(a.zmax, 1.0e6)) - 1;
+    a.k_safe = ks < 0 ? 0 : ks;
+    a.max_iter = (int)std::ceil(std::fmin(a.zmax, 1.0e6)) + 8;
+    a.w = h->w;
+    a.hit_xy = h->record_hits ? h->hit_xy : nullptr;
+    a.hit_cell = h->record_hits ? h->hit_cell : nullptr;
+    a.stats = h->stats;
+    a.luts = h->luts;
+    HIPCHK(hipMemsetAsync(h->stats, 0, 3 * sizeof(unsigned long long), h->stream));
+    slam_mcl::Span span(h, G_WEIGHTS);
+    if (slam_mode)
+    {
+        a.grid = h->maps;
+        hipLaunchKernelGGL(slamk::k_weights_S, dim3((unsigned)cdiv(h->n, 64)), dim3(64), 0, h->stream, a);
+    }
+    else if (h->prm.raycaster == SLAM_RAYCAST_FAST)
+    {
+        a.grid = h->clr;
+        hipLaunchKernelGGL(slamk::k_weights_L<0>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
+    }
+    else
+    {
+        a.grid = h->grid;
+        hipLaunchKernelGGL(slamk::k_weights_L<1>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    return SLAM_OK;
+}
+
+// running sums of the weights of all shards (n_glob entries) into lvl_P[0], in the configured order
+int do_prefix(slam_mcl* h, const slamk::StateView& view)
+{
+    if (h->prm.prefix_order == SLAM_PREFIX_REFERENCE)
+    {
+        // single shard only (checked by the caller): the weight column is contiguous
+        hipLaunchKernelGGL(slamk::k_prefix_seq, dim3(1), dim3(64), 0, h->stream, view.base + 3 * view.n_loc, h->n_glob,
+                           h->lvl_P[0]);
+        HIPCHK(hipGetLastError());
+        return SLAM_OK;
+    }
+    const int L = (int)h->lvl_n.size();
+    const double* in = nullptr;  // level 0 reads the weight column of the view
+    for (int l = 0; l < L; ++l)
+    {
+        const int64_t nl = h->lvl_n[l];
+        hipLaunchKernelGGL(slamk::k_scan_chunks, dim3((unsigned)cdiv(cdiv(nl, 64), 4)), dim3(256), 0, h->stream, in, view,
+                           nl, h->lvl_s[l], h->lvl_tot[l]);
+        in = h->lvl_tot[l];
+    }
+    // top level: P = s (same buffer, see create); lower levels add the earlier chunks' sum
+    for (int l = L - 2; l >= 0; --l)
+    {
+        const int64_t nl = h->lvl_n[l];
+        hipLaunchKernelGGL(slamk::k_downsweep, dim3((unsigned)cdiv(nl, 256)), dim3(256), 0, h->stream, h->lvl_s[l],
+                           h->lvl_P[l + 1], nl, h->lvl_P[l]);
+    }
+    HIPCHK(hipGetLastError());
+    return SLAM_OK;
+}
+
+// `gathered`: packed states of all shards ([n_shards][4][n]); nullptr = this handle alone.
+int do_resample(slam_mcl* h, const double* gathered, int n_shards)
+{
+    const bool injected = h->prm.noise == SLAM_NOISE_INJECTED;
+    if (injected && !h->have_uniforms) return fail(SLAM_ERR_STATE, "injected noise: no uniforms set for this update");
+    const int64_t n = h->n;
+    if ((int64_t)n_shards * n != h->n_glob)
+        return fail(SLAM_ERR_STATE, "resample: shards * n_particles != global_n (sharded handles must use slam_mcl_shard_resample)");
+    if (n_shards > 1 && (h->prm.sort != SLAM_SORT_NONE || h->prm.prefix_order != SLAM_PREFIX_BLOCKED ||
+                         h->prm.mode != SLAM_MODE_LOCALIZATION))
+        return fail(SLAM_ERR_STATE, "sharded resampling needs localization mode, SLAM_SORT_NONE and SLAM_PREFIX_BLOCKED");
+    slamk::StateView view;
+    view.base = gathered ? gathered : h->state;
+    view.n_loc = n;
+    {
+        slam_mcl::Span span(h, G_RESAMPLE);
+        int rc = do_prefix(h, view);
+        if (rc) return rc;
+        slamk::SelectArgs s;
+        s.P = h->lvl_P[0];
+        s.n_total = h->n_glob;
+        s.slot_first = h->prm.global_first;
+        s.n_slots = n;
+        s.injected = injected ? h->inj_uniforms : nullptr;
+        s.seed = h->prm.seed;
+        s.step = h->resample_step;
+        s.resampler = h->prm.resampler;
+        s.idx = h->idx;
+        hipLaunchKernelGGL(slamk::k_select, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, s);
+        HIPCHK(hipGetLastError());
+    }
+    const int32_t* perm = nullptr;
+    if (h->prm.sort == SLAM_SORT_FULL)
+    {
+        slam_mcl::Span span(h, G_SORT);
+        hipLaunchKernelGGL(slamk::k_sort_keys, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, view, h->idx, n,
+                           h->keys, h->slots);
+        size_t bytes = h->sort_tmp_bytes;
+        HIPCHK(rocprim::radix_sort_pairs_desc(h->sort_tmp, bytes, h->keys, h->keys2, h->slots, h->perm, (size_t)n, 0, 64,
+                                              h->stream));
+        perm = h->perm;
+    }
+    {
+        slam_mcl::Span span(h, G_RESAMPLE);
+        hipLaunchKernelGGL(slamk::k_gather, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, view, h->idx, perm, n,
+                           h->state2, h->src);
+        HIPCHK(hipGetLastError());
+    }
+    std::swap(h->state, h->state2);
+    h->bind();
+    if (h->prm.mode == SLAM_MODE_SLAM)
+    {
+        slam_mcl::Span span(h, G_CLONE);
+        const unsigned chunks = (unsigned)std::min<size_t>(cdiv((int64_t)(h->map_stride / 16), 256), 64);
+        hipLaunchKernelGGL(slamk::k_clone_maps, dim3(chunks, (unsigned)n), dim3(256), 0, h->stream, h->maps, h->maps2,
+                           h->src, h->map_stride);
+        HIPCHK(hipGetLastError());
+        std::swap(h->maps, h->maps2);
+    }
+    h->have_uniforms = false;
+    h->resample_step++;
+    return SLAM_OK;
+}
+
+int maybe_finish(slam_mcl* h)
+{
+    if (h->prm.async_launch) return SLAM_OK;
+    return finish(h);
+}
+}  // namespace
+
+SLAM_API const char* slam_last_error(void) { return g_err.c_str(); }
+SLAM_API int slam_version(void) { return 1; }
+
+SLAM_API void slam_mcl_destroy(slam_mcl* h)
+{
+    if (!h) return;
+    hipSetDevice(h->prm.device);
+    hipStreamSynchronize(h->stream);
+    for (auto& s : h->spans)
+    {
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    void* ptrs[] = {h->state, h->state2,
+                    h->grid,  h->clr,    h->maps, h->maps2,    h->luts,         h->angles, h->z2,   h->z,
+                    h->inj_normals, h->inj_uniforms, h->idx, h->perm, h->slots, h->src,   h->keys, h->keys2,
+                    h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    for (size_t l = 0; l < h->lvl_s.size(); ++l)
+    {
+        if (h->lvl_s[l]) hipFree(h->lvl_s[l]);
+        if (h->lvl_P[l] && h->lvl_P[l] != h->lvl_s[l]) hipFree(h->lvl_P[l]);
+        if (h->lvl_tot[l]) hipFree(h->lvl_tot[l]);
+    }
+    delete h;
+}
+
+SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
+{
+    if (!params || !out) return fail(SLAM_ERR_ARG, "null params/out");
+    *out = nullptr;
+    if (params->struct_size != (int32_t)sizeof(slam_mcl_params))
+        return fail(SLAM_ERR_ARG, "slam_mcl_params.struct_size mismatch (header/library version skew)");
+    if (params->n_particles <= 0 || params->n_particles >= 2147483647LL)
+        return fail(SLAM_ERR_ARG, "n_particles must be in [1, 2^31-1) (the reference indexes with int)");
+    if (params->rows <= 0 || params->cols <= 0 || params->rows > (1 << 20) || params->cols > (1 << 20) ||
+        (int64_t)params->rows * params->cols >= 2147483647LL)
+        return fail(SLAM_ERR_ARG, "rows/cols out of range");
+    if (params->mode != SLAM_MODE_LOCALIZATION && params->mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_ARG, "bad mode");
+    if (params->mode == SLAM_MODE_SLAM && params->raycaster == SLAM_RAYCAST_FAST && false) return SLAM_ERR_ARG;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (params->device < 0 || params->device >= ndev) return fail(SLAM_ERR_ARG, "device ordinal out of range");
+    HIPCHK(hipSetDevice(params->device));
+
+    slam_mcl* h = new (std::nothrow) slam_mcl();
+    if (!h) return fail(SLAM_ERR_NOMEM, "host allocation failed");
+    h->prm = *params;
+    if (h->prm.global_n <= 0)
+    {
+        h->prm.global_n = params->n_particles;
+        h->prm.global_first = 0;
+    }
+    h->stream = reinterpret_cast<hipStream_t>(params->stream);
+    h->n = params->n_particles;
+    h->rows = params->rows;
+    h->cols = params->cols;
+    const int64_t n = h->n;
+    int rc = SLAM_OK;
+#define TRY(e)                  \
+    if (!rc) rc = (e)
+    h->n_glob = h->prm.global_n;
+    if (h->prm.global_first < 0 || h->prm.global_first + n > h->n_glob || h->n_glob >= 2147483647LL)
+        rc = fail(SLAM_ERR_ARG, "global_first/global_n do not contain this shard");
+    TRY(dev_alloc(&h->state, 4 * n));
+    TRY(dev_alloc(&h->state2, 4 * n));
+    if (!rc) h->bind();
+    TRY(dev_alloc(&h->idx, n));
+    TRY(dev_alloc(&h->perm, n));
+    TRY(dev_alloc(&h->slots, n));
+    TRY(dev_alloc(&h->src, n));
+    TRY(dev_alloc(&h->keys, n));
+    TRY(dev_alloc(&h->keys2, n));
+    TRY(dev_alloc(&h->stats, 3));
+    TRY(dev_alloc(&h->luts, 512));
+    TRY(dev_alloc(&h->partials, 4 * (size_t)cdiv(n, 256)));
+    if (!rc && h->n_glob != n && (h->prm.sort != SLAM_SORT_NONE || h->prm.prefix_order != SLAM_PREFIX_BLOCKED))
+        rc = fail(SLAM_ERR_ARG, "a shard (global_n > n_particles) needs SLAM_SORT_NONE and SLAM_PREFIX_BLOCKED");
+    if (h->prm.noise == SLAM_NOISE_INJECTED)
+    {
+        TRY(dev_alloc(&h->inj_normals, 3 * n));
+        TRY(dev_alloc(&h->inj_uniforms, n));
+    }
+    // running-sum hierarchy
+    if (!rc)
+    {
+        int64_t nl = h->n_glob;  // every shard builds the running sum of the whole filter
+        for (;;)
+        {
+            h->lvl_n.push_back(nl);
+            if (nl <= 64) break;
+            nl = cdiv(nl, 64);
+        }
+        const size_t L = h->lvl_n.size();
+        h->lvl_s.assign(L, nullptr);
+        h->lvl_P.assign(L, nullptr);
+        h->lvl_tot.assign(L, nullptr);
+        for (size_t l = 0; l < L && !rc; ++l)
+        {
+            TRY(dev_alloc(&h->lvl_s[l], h->lvl_n[l]));
+            TRY(dev_alloc(&h->lvl_tot[l], cdiv(h->lvl_n[l], 64)));
+            if (l + 1 == L && h->prm.prefix_order == SLAM_PREFIX_BLOCKED)
+                h->lvl_P[l] = h->lvl_s[l];
+            else
+                TRY(dev_alloc(&h->lvl_P[l], h->lvl_n[l]));
+        }
+    }
+    if (!rc && h->prm.sort == SLAM_SORT_FULL)
+    {
+        size_t bytes = 0;
+        hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, bytes, h->keys, h->keys2, h->slots, h->perm, (size_t)n, 0,
+                                                      64, h->stream);
+        if (e != hipSuccess)
+            rc = fail(SLAM_ERR_HIP, std::string("radix sort size query: ") + hipGetErrorString(e));
+        else
+        {
+            h->sort_tmp_bytes = bytes;
+            uint8_t* tmp = nullptr;
+            TRY(dev_alloc(&tmp, bytes ? bytes : 16));
+            h->sort_tmp = tmp;
+        }
+    }
+    if (!rc)
+    {
+        uint8_t t[512];
+        build_luts(t);
+        if (hipMemcpy(h->luts, t, 512, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SLAM_ERR_HIP, "lut upload");
+    }
+    if (!rc && h->prm.mode == SLAM_MODE_SLAM)
+    {
+        h->map_stride = ((size_t)h->rows * h->cols + 255) / 256 * 256;
+        TRY(dev_alloc(&h->maps, h->map_stride * (size_t)n));
+        TRY(dev_alloc(&h->maps2, h->map_stride * (size_t)n));
+        // slam/mcl.cpp:30: blank canvas of 128
+        if (!rc && hipMemsetAsync(h->maps, 128, h->map_stride * (size_t)n, h->stream) != hipSuccess)
+            rc = fail(SLAM_ERR_HIP, "canvas fill");
+        if (!rc && hipMemsetAsync(h->maps2, 128, h->map_stride * (size_t)n, h->stream) != hipSuccess)
+            rc = fail(SLAM_ERR_HIP, "canvas fill");
+    }
+    if (!rc)
+    {
+        // slam/mcl.cpp:22-25,31-36: canvas centre, heading pi/2, uniform weight
+        hipLaunchKernelGGL(slamk::k_fill_poses, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, n, h->x, h->y,
+                           h->th, h->w, h->cols / 2.0, h->rows / 2.0, M_PI / 2, 1.0 / (double)h->prm.global_n);
+        rc = finish(h);
+    }
+#undef TRY
+    if (rc)
+    {
+        std::string keep = g_err;
+        slam_mcl_destroy(h);
+        g_err = keep;
+        return rc;
+    }
+    *out = h;
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_set_map_u8(slam_mcl* h, const uint8_t* map, int32_t rows, int32_t cols)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_LOCALIZATION) return fail(SLAM_ERR_STATE, "set_map_u8 is for localization mode");
+    if (!map || rows != h->rows || cols != h->cols) return fail(SLAM_ERR_ARG, "map null or size differs from create()");
+    const size_t bytes = (size_t)rows * cols;
+    if (!h->grid)
+    {
+        if ((rc = dev_alloc(&h->grid, bytes)) || (rc = dev_alloc(&h->clr, bytes))) return rc;
+    }
+    std::vector<uint8_t> E(bytes);
+    slam_build_clearance(map, rows, cols, E.data());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->grid, map, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->clr, E.data(), bytes, hipMemcpyHostToDevice));
+    h->have_map = true;
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_set_poses(slam_mcl* h, const double* x, const double* y, const double* theta, int64_t first,
+                                int64_t count)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!x || !y || !theta || first < 0 || count < 0 || first + count > h->n) return fail(SLAM_ERR_ARG, "set_poses: bad range");
+    for (int64_t k = 0; k < count; ++k)
+        if (!std::isfinite(x[k]) || !std::isfinite(y[k]) || !std::isfinite(theta[k]))
+            return fail(SLAM_ERR_ARG, "set_poses: non-finite pose");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->x + first, x, sizeof(double) * count, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->y + first, y, sizeof(double) * count, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->th + first, theta, sizeof(double) * count, hipMemcpyHostToDevice));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_set_weights(slam_mcl* h, const double* w, int64_t first, int64_t count)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!w || first < 0 || count < 0 || first + count > h->n) return fail(SLAM_ERR_ARG, "set_weights: bad range");
+    for (int64_t k = 0; k < count; ++k)
+        if (!(w[k] >= 0) || !std::isfinite(w[k])) return fail(SLAM_ERR_ARG, "set_weights: weights must be finite and >= 0");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->w + first, w, sizeof(double) * count, hipMemcpyHostToDevice));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_seed_gaussian(slam_mcl* h, const double mean[3], const double sigma[3])
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!mean || !sigma) return fail(SLAM_ERR_ARG, "seed_gaussian: null");
+    for (int k = 0; k < 3; ++k)
+        if (!std::isfinite(mean[k]) || !std::isfinite(sigma[k]) || sigma[k] < 0) return fail(SLAM_ERR_ARG, "seed_gaussian: bad value");
+    hipLaunchKernelGGL(slamk::k_seed_gaussian, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->y,
+                       h->th, h->w, mean[0], mean[1], mean[2], sigma[0], sigma[1], sigma[2], h->prm.seed,
+                       (uint64_t)h->prm.global_first, 1.0 / (double)h->prm.global_n);
+    return finish(h);
+}
+
+SLAM_API int slam_mcl_set_maps_u8(slam_mcl* h, const uint8_t* maps, int64_t first, int64_t count)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "set_maps_u8 is for SLAM mode");
+    if (!maps || first < 0 || count < 0 || first + count > h->n) return fail(SLAM_ERR_ARG, "set_maps_u8: bad range");
+    const size_t bytes = (size_t)h->rows * h->cols;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy2D(h->maps + h->map_stride * (size_t)first, h->map_stride, maps, bytes, bytes, (size_t)count,
+                       hipMemcpyHostToDevice));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_set_noise(slam_mcl* h, const double* unit_normals, const double* canonical_uniforms)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.noise != SLAM_NOISE_INJECTED) return fail(SLAM_ERR_STATE, "handle was not created with SLAM_NOISE_INJECTED");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (unit_normals)
+    {
+        for (int64_t k = 0; k < 3 * h->n; ++k)
+            if (!std::isfinite(unit_normals[k])) return fail(SLAM_ERR_ARG, "set_noise: non-finite normal");
+        HIPCHK(hipMemcpy(h->inj_normals, unit_normals, sizeof(double) * 3 * h->n, hipMemcpyHostToDevice));
+        h->have_normals = true;
+    }
+    if (canonical_uniforms)
+    {
+        for (int64_t k = 0; k < h->n; ++k)
+            if (!(canonical_uniforms[k] >= 0.0 && canonical_uniforms[k] < 1.0))
+                return fail(SLAM_ERR_ARG, "set_noise: uniforms must lie in [0,1)");
+        HIPCHK(hipMemcpy(h->inj_uniforms, canonical_uniforms, sizeof(double) * h->n, hipMemcpyHostToDevice));
+        h->have_uniforms = true;
+    }
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_predict(slam_mcl* h, const double odom[3], const double alphas[4])
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!odom || !alphas) return fail(SLAM_ERR_ARG, "predict: null");
+    for (int k = 0; k < 3; ++k)
+        if (!std::isfinite(odom[k])) return fail(SLAM_ERR_ARG, "predict: non-finite odometry");
+    for (int k = 0; k < 4; ++k)
+        if (!std::isfinite(alphas[k]) || alphas[k] < 0) return fail(SLAM_ERR_ARG, "predict: alphas must be finite and >= 0");
+    const bool injected = h->prm.noise == SLAM_NOISE_INJECTED;
+    if (injected && !h->have_normals) return fail(SLAM_ERR_STATE, "injected noise: no normals set for this predict");
+    slamk::PredictArgs a;
+    a.n = h->n;
+    a.x = h->x;
+    a.y = h->y;
+    a.th = h->th;
+    a.r1 = odom[0];
+    a.t = odom[1];
+    a.r2 = odom[2];
+    // slam/motion.cpp:15-25 (std::pow(v, 2) is v*v)
+    a.s1 = std::sqrt(alphas[0] * (a.r1 * a.r1) + alphas[1] * (a.t * a.t));
+    a.st = std::sqrt(alphas[2] * (a.t * a.t) + alphas[3] * ((a.r1 * a.r1) + (a.r2 * a.r2)));
+    a.s2 = std::sqrt(alphas[0] * (a.r2 * a.r2) + alphas[1] * (a.t * a.t));
+    a.seed = h->prm.seed;
+    a.step = h->predict_step;
+    a.global_first = (uint64_t)h->prm.global_first;
+    a.injected = injected ? h->inj_normals : nullptr;
+    {
+        slam_mcl::Span span(h, G_PREDICT);
+        hipLaunchKernelGGL(slamk::k_predict, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    h->predict_step++;
+    h->have_normals = false;
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_update_weights(slam_mcl* h, const double* angles, const double* dists, int32_t n_beams,
+                                     double stddev, double max_dist, const double scanner_offset[3])
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if ((rc = upload_scan(h, angles, dists, n_beams))) return rc;
+    if ((rc = do_weights(h, n_beams, stddev, max_dist, scanner_offset))) return rc;
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_resample(slam_mcl* h)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if ((rc = do_resample(h, nullptr, 1))) return rc;
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_shard_resample(slam_mcl* h, const double* gathered_state_dev, int32_t n_shards)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!gathered_state_dev || n_shards < 1) return fail(SLAM_ERR_ARG, "shard_resample: null buffer or n_shards < 1");
+    if (h->n % 64) return fail(SLAM_ERR_STATE, "sharded resampling needs n_particles % 64 == 0 on every shard");
+    if ((rc = do_resample(h, gathered_state_dev, n_shards))) return rc;
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_update(slam_mcl* h, const double* angles, const double* dists, int32_t n_beams, double stddev,
+                             double max_dist, const double scanner_offset[3])
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if ((rc = upload_scan(h, angles, dists, n_beams))) return rc;
+    if ((rc = do_weights(h, n_beams, stddev, max_dist, scanner_offset))) return rc;
+    if ((rc = do_resample(h, nullptr, 1))) return rc;
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_get_poses(slam_mcl* h, double* x, double* y, double* theta, int64_t first, int64_t count)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!x || !y || !theta || first < 0 || count < 0 || first + count > h->n) return fail(SLAM_ERR_ARG, "get_poses: bad range");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(x, h->x + first, sizeof(double) * count, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(y, h->y + first, sizeof(double) * count, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(theta, h->th + first, sizeof(double) * count, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_get_weights(slam_mcl* h, double* w, int64_t first, int64_t count)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!w || first < 0 || count < 0 || first + count > h->n) return fail(SLAM_ERR_ARG, "get_weights: bad range");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(w, h->w + first, sizeof(double) * count, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_get_map_u8(slam_mcl* h, int64_t particle, uint8_t* map)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "get_map_u8 is for SLAM mode");
+    if (!map || particle < 0 || particle >= h->n) return fail(SLAM_ERR_ARG, "get_map_u8: bad particle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(map, h->maps + h->map_stride * (size_t)particle, (size_t)h->rows * h->cols, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_get_last_indices(slam_mcl* h, int32_t* idx)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!idx) return fail(SLAM_ERR_ARG, "null");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(idx, h->idx, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_get_last_order(slam_mcl* h, int32_t* perm)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!perm) return fail(SLAM_ERR_ARG, "null");
+    if (h->prm.sort != SLAM_SORT_FULL) return fail(SLAM_ERR_STATE, "handle was created without the sort");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(perm, h->perm, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_get_prefix(slam_mcl* h, double* prefix, double* sum)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (prefix) HIPCHK(hipMemcpy(prefix, h->lvl_P[0], sizeof(double) * h->n_glob, hipMemcpyDeviceToHost));
+    if (sum) HIPCHK(hipMemcpy(sum, h->lvl_P[0] + (h->n_glob - 1), sizeof(double), hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_record_hits(slam_mcl* h, int32_t enable)
+{
+    if (!h) return fail(SLAM_ERR_ARG, "null handle");
+    h->record_hits = enable != 0;
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_get_hits(slam_mcl* h, double* hit_xy, int32_t* hit_cell)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!h->record_hits || !h->hit_xy || h->last_B <= 0) return fail(SLAM_ERR_STATE, "no hits recorded");
+    const size_t m = (size_t)h->n * h->last_B;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (hit_xy) HIPCHK(hipMemcpy(hit_xy, h->hit_xy, sizeof(double) * 2 * m, hipMemcpyDeviceToHost));
+    if (hit_cell) HIPCHK(hipMemcpy(hit_cell, h->hit_cell, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_average_pose(slam_mcl* h, double out[3])
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out) return fail(SLAM_ERR_ARG, "null");
+    const int64_t nb = cdiv(h->n, 256);
+    hipLaunchKernelGGL(slamk::k_pose_partials, dim3((unsigned)nb), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th,
+                       h->partials);
+    HIPCHK(hipGetLastError());
+    std::vector<double> part(4 * (size_t)nb);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(part.data(), h->partials, sizeof(double) * part.size(), hipMemcpyDeviceToHost));
+    double s[4] = {0, 0, 0, 0};
+    for (int64_t b = 0; b < nb; ++b)
+        for (int q = 0; q < 4; ++q) s[q] += part[4 * (size_t)b + q];
+    out[0] = s[0] / (double)h->n;  // slam/util.cpp:80-82
+    out[1] = s[1] / (double)h->n;
+    out[2] = std::atan2(s[3], s[2]);
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_get_stats(slam_mcl* h, int64_t out[3])
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out) return fail(SLAM_ERR_ARG, "null");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long t[3];
+    HIPCHK(hipMemcpy(t, h->stats, sizeof(t), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) out[k] = (int64_t)t[k];
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_profile(slam_mcl* h, int32_t enable)
+{
+    if (!h) return fail(SLAM_ERR_ARG, "null handle");
+    h->profile = enable != 0;
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_get_kernel_ms(slam_mcl* h, double ms[5], int64_t launches[5], int32_t reset)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (auto& s : h->spans)
+    {
+        float t = 0;
+        if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess)
+        {
+            h->acc_ms[s.group] += t;
+            h->acc_launches[s.group]++;
+        }
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    h->spans.clear();
+    for (int k = 0; k < G_COUNT; ++k)
+    {
+        if (ms) ms[k] = h->acc_ms[k];
+        if (launches) launches[k] = h->acc_launches[k];
+        if (reset)
+        {
+            h->acc_ms[k] = 0;
+            h->acc_launches[k] = 0;
+        }
+    }
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_synchronize(slam_mcl* h)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    return finish(h);
+}
+
+SLAM_API int slam_mcl_device_state_get(slam_mcl* h, slam_mcl_device_state* out)
+{
+    if (!h || !out) return fail(SLAM_ERR_ARG, "null");
+    out->state_dev = h->state;
+    out->prefix_dev = h->lvl_P[0];
+    out->n_particles = h->n;
+    out->global_n = h->n_glob;
+    return SLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace
+{
+template <int KIND>
+int raycast_batch(int device, const uint8_t* map, int rows, int cols, const std::vector<double>& px,
+                  const std::vector<double>& py, const std::vector<double>& pth, double max2, double step, double* hits)
+{
+    const int64_t n = (int64_t)px.size();
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(SLAM_ERR_ARG, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    if (!map || rows <= 0 || cols <= 0 || !hits || !(step > 0) || !(max2 >= 0) || !std::isfinite(max2))
+        return fail(SLAM_ERR_ARG, "raycast: bad argument");
+    for (int64_t k = 0; k < n; ++k)
+        if (!std::isfinite(px[k]) || !std::isfinite(py[k]) || !std::isfinite(pth[k])) return fail(SLAM_ERR_ARG, "raycast: non-finite pose");
+    uint8_t* dmap = nullptr;
+    double *dx = nullptr, *dy = nullptr, *dth = nullptr, *dh = nullptr;
+    int rc = SLAM_OK;
+    if ((rc = dev_alloc(&dmap, (size_t)rows * cols)) || (rc = dev_alloc(&dx, n)) || (rc = dev_alloc(&dy, n)) ||
+        (rc = dev_alloc(&dth, n)) || (rc = dev_alloc(&dh, 2 * n)))
+    {
+        hipFree(dmap); hipFree(dx); hipFree(dy); hipFree(dth); hipFree(dh);
+        return rc;
+    }
+    hipError_t e = hipMemcpy(dmap, map, (size_t)rows * cols, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dx, px.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dy, py.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dth, pth.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+    {
+        const double reach = std::fmin(std::sqrt(max2) / step, 1.0e8);
+        const int max_iter = (int)std::ceil(reach) + 8;
+        hipLaunchKernelGGL(slamk::k_raycast_ro<KIND>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, 0, dmap, rows, cols, n,
+                           dx, dy, dth, max2, step, max_iter, dh);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(hits, dh, sizeof(double) * 2 * n, hipMemcpyDeviceToHost);
+    hipFree(dmap); hipFree(dx); hipFree(dy); hipFree(dth); hipFree(dh);
+    if (e != hipSuccess) return fail(SLAM_ERR_HIP, std::string("raycast batch: ") + hipGetErrorString(e));
+    return SLAM_OK;
+}
+}  // namespace
+
+SLAM_API int slam_fake_lidar_scan(int32_t device, const uint8_t* map01, int32_t rows, int32_t cols, const double* poses3,
+                                  int32_t n_poses, double start, double stop, double max_dist, int32_t n_rays,
+                                  double* hits_xy)
+{
+    if (!poses3 || n_poses <= 0 || n_rays <= 0) return fail(SLAM_ERR_ARG, "fake_lidar_scan: bad argument");
+    // slam/fake_lidar.cpp:17-30: theta starts at pose.theta - range/2 and ACCUMULATES by += step
+    const double range = stop - start;
+    const double step = range / n_rays;
+    const size_t n = (size_t)n_poses * n_rays;
+    std::vector<double> px(n), py(n), pth(n);
+    for (int p = 0; p < n_poses; ++p)
+    {
+        double theta = poses3[3 * p + 2];
+        theta -= range / 2;
+        for (int r = 0; r < n_rays; ++r)
+        {
+            px[(size_t)p * n_rays + r] = poses3[3 * p];
+            py[(size_t)p * n_rays + r] = poses3[3 * p + 1];
+            pth[(size_t)p * n_rays + r] = theta;
+            theta += step;
+        }
+    }
+    return raycast_batch<2>(device, map01, rows, cols, px, py, pth, max_dist * max_dist, 0.5, hits_xy);
+}
+
+SLAM_API int slam_raycast_u8(int32_t device, const uint8_t* map, int32_t rows, int32_t cols, const double* poses3,
+                             int64_t n, double max_distance_squared, double step_size, double* hits_xy)
+{
+    if (!poses3 || n <= 0) return fail(SLAM_ERR_ARG, "raycast_u8: bad argument");
+    std::vector<double> px(n), py(n), pth(n);
+    for (int64_t k = 0; k < n; ++k)
+    {
+        px[k] = poses3[3 * k];
+        py[k] = poses3[3 * k + 1];
+        pth[k] = poses3[3 * k + 2];
+    }
+    return raycast_batch<1>(device, map, rows, cols, px, py, pth, max_distance_squared, step_size, hits_xy);
+}

@@ -1,0 +1,57 @@
+"""The C-ABI library loads on a CPU-only machine and exports every symbol include/*.h declares."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = []
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names += re.findall(r"\b(slam_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_declares_something():
+    assert len(declared_symbols()) >= 25
+
+
+def test_library_exports_every_declared_symbol():
+    from slam_amd import capi
+
+    lib = capi.load_library()
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert set(declared_symbols()) == set(capi.SYMBOLS), "capi.SYMBOLS out of sync with include/slam_hip.h"
+    assert lib.slam_version() >= 1
+
+
+def test_params_struct_layout_matches_header():
+    from slam_amd import capi
+
+    # field order/sizes of slam_mcl_params in include/slam_hip.h
+    assert ctypes.sizeof(capi.Params) == 88
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product must fail loudly, not compute on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import slam_amd
+
+    with pytest.raises(slam_amd.SlamError):
+        slam_amd.Filter(16, 8, 8)
+
+
+def test_product_never_imports_the_oracle():
+    for path in glob.glob(os.path.join(ROOT, "slam_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".h", ".hip", ".cpp")):
+            text = open(path, errors="ignore").read()
+            assert "oracle/" not in text and "_oracle" not in text and "liboracle" not in text, path

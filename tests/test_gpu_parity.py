@@ -1,0 +1,488 @@
+"""GPU parity: every call goes through the C ABI (libslam_hip.so) and is compared with the CPU oracle
+on the same seeded inputs and the same injected noise streams.
+
+Bar (BASELINE.json north_star): raycast hit cells, grid updates and resampled indices bit-exact;
+weights and poses within 1e-5 relative.  Against the oracle's detmath mode (same elementary
+functions as the kernels) EVERYTHING is compared bit for bit, weights and poses included; against
+its glibc mode (what the reference calls) the integer results are compared exactly and the
+floating-point ones with the stated tolerance.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5  # north_star tolerance for weights and poses
+ODOM = [2.5, 0.02, 0.02]            # benchmark/mcl.cpp:60
+ALPHAS = [5e-4, 5e-4, 1e-2, 1e-2]   # benchmark/mcl.cpp:61
+OFFSET = [0.0, 30.0, 0.0]           # benchmark/mcl.cpp:28
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import slam_amd
+
+    slam_amd.load_library()
+    return slam_amd
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bits(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    bad = np.flatnonzero(bits(a).ravel() != bits(b).ravel())
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} values differ bitwise, first at {bad[:5]}: {a.ravel()[bad[:3]]} vs {b.ravel()[bad[:3]]}"
+
+
+def grid_of(name):
+    return (orc.load_map(name) * 255).astype(np.uint8)
+
+
+def cloud(rng, n, cx, cy, sxy=25.0, sth=0.2, th0=0.3):
+    return cx + sxy * rng.standard_normal(n), cy + sxy * rng.standard_normal(n), th0 + sth * rng.standard_normal(n)
+
+
+# ---- K1 motion ------------------------------------------------------------------------------------
+def test_predict_injected_normals(sa):
+    rng = np.random.default_rng(11)
+    N = 5000
+    x, y, th = rng.uniform(0, 1000, N), rng.uniform(0, 1000, N), rng.uniform(-2 * np.pi, np.pi, N)
+    f = sa.Filter(N, 100, 100, noise=sa.capi.NOISE_INJECTED)
+    f.set_poses(x, y, th)
+    gx, gy, gth = x, y, th
+    for step in range(4):
+        z = orc.reference_normals(3 * N, tick0=1000 * step + 1, tick_stride=1)  # libstdc++ draws, slam/util.cpp:27-34
+        f.set_noise(unit_normals=z)
+        f.predict(ODOM, ALPHAS)
+        ox, oy, oth = orc.predict(gx, gy, gth, ODOM, ALPHAS, z, math=orc.DET)
+        lx, ly, lth = orc.predict(gx, gy, gth, ODOM, ALPHAS, z, math=orc.LIBM)
+        px, py, pth = f.poses()
+        assert_bits(px, ox, "x"), assert_bits(py, oy, "y"), assert_bits(pth, oth, "theta")
+        assert np.allclose(px, lx, rtol=REL_TOL) and np.allclose(py, ly, rtol=REL_TOL) and np.allclose(pth, lth, rtol=REL_TOL, atol=1e-12)
+        gx, gy, gth = ox, oy, oth
+    f.close()
+
+
+def test_predict_philox_matches_host_stream_and_shards(sa):
+    N = 4096
+    seed = 0xABCDEF01
+    f = sa.Filter(N, 64, 64, seed=seed)
+    x0, y0, th0 = f.poses()
+    halves = [sa.Filter(N // 2, 64, 64, seed=seed, global_first=k * N // 2, global_n=N) for k in range(2)]
+    gx, gy, gth = x0, y0, th0
+    for step in range(3):
+        f.predict(ODOM, ALPHAS)
+        for hf in halves:
+            hf.predict(ODOM, ALPHAS)
+        z = orc.philox_normals(seed, step, 0, N)
+        gx, gy, gth = orc.predict(gx, gy, gth, ODOM, ALPHAS, z, math=orc.DET)
+        px, py, pth = f.poses()
+        assert_bits(px, gx, "x"), assert_bits(py, gy, "y"), assert_bits(pth, gth, "theta")
+        hx = np.concatenate([hf.poses()[0] for hf in halves])
+        assert_bits(hx, gx, "sharded x")
+    for h in [f] + halves:
+        h.close()
+
+
+# ---- K2a raycast + likelihood, localization mode -------------------------------------------------
+@pytest.mark.parametrize("raycaster", ["fast", "walk"])
+@pytest.mark.parametrize("mapname,N,B,zmax,stddev", [("floor_plan", 600, 360, 500.0, 5.0), ("map", 300, 90, 500.0, 5.0),
+                                                     ("maze", 200, 65, 150.5, 2.0), ("floor_plan", 128, 1, 40.0, 5.0)])
+def test_weights_localization(sa, raycaster, mapname, N, B, zmax, stddev):
+    rng = np.random.default_rng(zlib.crc32(f"{mapname}-{N}-{B}".encode()))
+    free = orc.load_map(mapname)
+    g = (free * 255).astype(np.uint8)
+    rows, cols = g.shape
+    true = [cols * 0.4, rows * 0.45, 0.3]
+    ang, dist = orc.make_scan(free, true, OFFSET, B, max_dist=zmax)
+    x, y, th = cloud(rng, N, true[0], true[1])
+    x[:8] = rng.uniform(-60, cols + 60, 8)   # some particles outside / at the border
+    y[:8] = rng.uniform(-60, rows + 60, 8)
+    f = sa.Filter(N, rows, cols, raycaster=sa.capi.RAYCAST_FAST if raycaster == "fast" else sa.capi.RAYCAST_WALK)
+    f.set_map(g)
+    f.set_poses(x, y, th)
+    f.record_hits(True)
+    f.update_weights(ang, dist, stddev, zmax, OFFSET)
+    w = f.weights()
+    hxy, hcell = f.hits()
+    ow, oxy, ocell, ost = orc.update_weights(x, y, th, g, ang, dist, stddev, zmax, OFFSET, want_hits=True, math=orc.DET)
+    assert np.array_equal(hcell, ocell), f"{np.sum(hcell != ocell)} hit cells differ"
+    assert_bits(hxy, oxy, "hit positions")
+    assert_bits(w, ow, "weights")
+    if raycaster == "walk":
+        assert f.stats() == ost
+    # against glibc (the reference's own libm): integer results exact up to rare last-bit cell flips
+    lw, lxy, lcell, _ = orc.update_weights(x, y, th, g, ang, dist, stddev, zmax, OFFSET, want_hits=True, math=orc.LIBM)
+    flips = int(np.sum(hcell != lcell))
+    assert flips <= max(1, N * B // 20000), f"{flips} of {N * B} hit cells differ from the glibc oracle"
+    ok = (lw > 1e-290) & (np.all(hcell == lcell, axis=1))
+    assert np.allclose(w[ok], lw[ok], rtol=REL_TOL)
+    f.close()
+
+
+def test_weights_degenerate_underflow_and_tiny_ranges(sa):
+    rng = np.random.default_rng(5)
+    g = grid_of("floor_plan")
+    rows, cols = g.shape
+    N = 64
+    x, y, th = cloud(rng, N, 500, 300)
+    f = sa.Filter(N, rows, cols)
+    f.set_map(g)
+    f.set_poses(x, y, th)
+    # sigma = 5 and B = 720 -> exp underflows to exactly 0 for every particle (SURVEY.md §7 hard part 4)
+    ang = np.linspace(-np.pi, np.pi, 720, endpoint=False)
+    f.update_weights(ang, np.full(720, 100.0), 5.0, 500.0, OFFSET)
+    assert np.all(f.weights() == 0.0)
+    f.resample()
+    assert np.all(f.last_indices() == (N - 1) // 2)
+    # z == zmax, zmax < 1, zmax = 0
+    f.set_poses(x, y, th)
+    for zmax in (0.0, 0.6, 1.0, 2.5, 37.0):
+        d = np.full(33, zmax)
+        f.update_weights(ang[:33], d, 1.5, zmax, [0.5, 0.5, 0.25])
+        ow, _ = orc.update_weights(x, y, th, g, ang[:33], d, 1.5, zmax, [0.5, 0.5, 0.25], math=orc.DET)
+        assert_bits(f.weights(), ow, f"weights zmax={zmax}")
+    f.close()
+
+
+# ---- K2b SLAM mode: raycast + likelihood + occupancy update ---------------------------------------
+def test_weights_slam_mode_maps_bit_exact(sa):
+    rng = np.random.default_rng(21)
+    N, B, rows, cols = 48, 90, 300, 400
+    free = orc.load_map("map")
+    ang, dist = orc.make_scan(free, [400.0, 400.0, np.pi / 90], OFFSET, B)
+    f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM)
+    x, y, th = cloud(rng, N, cols / 2, rows / 2, sxy=6.0, sth=0.3, th0=np.pi / 2)
+    f.set_poses(x, y, th)
+    maps = np.full((N, rows, cols), 128, np.uint8)
+    f.record_hits(True)
+    for it in range(3):  # repeated scans: later passes see earlier writes (hits appear from pass 2 on)
+        f.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+        ow, oxy, ocell, ost = orc.update_weights(x, y, th, maps, ang, dist, 5.0, 500.0, OFFSET, slam_mode=True,
+                                                 want_hits=True, math=orc.DET)
+        hxy, hcell = f.hits()
+        assert np.array_equal(hcell, ocell)
+        assert_bits(hxy, oxy, "hit positions")
+        assert_bits(f.weights(), ow, "weights")
+        assert f.stats() == ost
+        for p in range(N):
+            assert np.array_equal(f.map_of(p), maps[p]), f"map of particle {p} differs after pass {it}"
+        if it:
+            assert (ocell >= 0).any()
+    f.close()
+
+
+# ---- K3/K4 resampling -------------------------------------------------------------------------------
+@pytest.mark.parametrize("order", ["blocked", "reference"])
+@pytest.mark.parametrize("N", [1, 2, 64, 65, 4096, 4097, 100000])
+def test_resample_indices_bit_exact(sa, order, N):
+    rng = np.random.default_rng(N)
+    w = rng.uniform(0, 1, N) ** 6
+    w[rng.uniform(size=N) < 0.15] = 0.0
+    if N > 10:
+        w[:5] = 0.0  # leading zeros: the equality branch of slam/mcl.cpp:187-191 is reachable with cutoff 0
+    u = orc.reference_uniforms(N, tick=N + 17)  # libstdc++ canonical uniforms
+    u[N // 2] = 0.0
+    f = sa.Filter(N, 16, 16, noise=sa.capi.NOISE_INJECTED,
+                  prefix_order=sa.capi.PREFIX_BLOCKED if order == "blocked" else sa.capi.PREFIX_REFERENCE)
+    x, y, th = rng.uniform(0, 16, N), rng.uniform(0, 16, N), rng.uniform(-1, 1, N)
+    f.set_poses(x, y, th)
+    f.set_weights(w)
+    f.set_noise(canonical_uniforms=u)
+    f.resample()
+    oidx, oP, osum = orc.resample(w, u, orc.ORDER_BLOCKED if order == "blocked" else orc.ORDER_REFERENCE)
+    P, s = f.prefix()
+    assert_bits(P, oP, "running sums")
+    assert bits([s])[0] == bits([osum])[0]
+    idx = f.last_indices()
+    assert np.array_equal(idx, oidx)
+    # the other order selects the same particles (a draw would have to fall between two roundings)
+    other, _, _ = orc.resample(w, u, orc.ORDER_REFERENCE if order == "blocked" else orc.ORDER_BLOCKED)
+    assert np.array_equal(idx, other)
+    # sort: (weight desc, slot asc); state = old[idx[perm]]
+    perm = f.last_order()
+    assert np.array_equal(perm, orc.sort_order(w[oidx], 0))
+    src = oidx[perm]
+    px, py, pth = f.poses()
+    assert_bits(px, x[src], "x"), assert_bits(py, y[src], "y"), assert_bits(pth, th[src], "theta")
+    nw = f.weights()
+    assert_bits(nw, w[src], "weights")
+    assert np.all(np.diff(nw) <= 0)  # slam/mcl.cpp:236-238 invariant
+    ref_perm = orc.sort_order(w[oidx], 1)  # the reference's unstable std::sort: same multiset, same front
+    assert np.array_equal(w[oidx][ref_perm], nw)
+    f.close()
+
+
+def test_resample_all_zero_and_single_survivor(sa):
+    for N in (9, 1000):
+        f = sa.Filter(N, 16, 16, noise=sa.capi.NOISE_INJECTED)
+        f.set_weights(np.zeros(N))
+        f.set_noise(canonical_uniforms=orc.reference_uniforms(N, 3))
+        f.resample()
+        assert np.all(f.last_indices() == (N - 1) // 2)
+        w = np.zeros(N)
+        w[N // 3] = 1e-300
+        f.set_weights(w)
+        u = orc.reference_uniforms(N, 4)
+        f.set_noise(canonical_uniforms=u)
+        f.resample()
+        assert np.array_equal(f.last_indices(), orc.resample(w, u, orc.ORDER_BLOCKED)[0])
+        f.close()
+
+
+def test_systematic_resampler(sa):
+    N = 5000
+    rng = np.random.default_rng(3)
+    w = rng.uniform(0, 1, N)
+    f = sa.Filter(N, 16, 16, noise=sa.capi.NOISE_INJECTED, resampler=sa.capi.RESAMPLE_SYSTEMATIC, sort=sa.capi.SORT_NONE)
+    f.set_weights(w)
+    u = np.full(N, 0.37)
+    f.set_noise(canonical_uniforms=u)
+    f.resample()
+    assert np.array_equal(f.last_indices(), orc.resample(w, u, orc.ORDER_BLOCKED, resampler=1)[0])
+    f.close()
+
+
+# ---- whole steps ------------------------------------------------------------------------------------
+def run_oracle_step(state, maps, g, ang, dist, stddev, zmax, z, u, slam, order):
+    x, y, th = orc.predict(state[0], state[1], state[2], ODOM, ALPHAS, z, math=orc.DET)
+    if slam:
+        w, _ = orc.update_weights(x, y, th, maps, ang, dist, stddev, zmax, OFFSET, slam_mode=True, math=orc.DET)
+    else:
+        w, _ = orc.update_weights(x, y, th, g, ang, dist, stddev, zmax, OFFSET, math=orc.DET)
+    idx, _, _ = orc.resample(w, u, order)
+    perm = orc.sort_order(w[idx], 0)
+    src = idx[perm]
+    if slam:
+        maps[:] = maps[src]
+    return (x[src], y[src], th[src], w[src]), idx
+
+
+def test_slam_loop_like_the_reference_benchmark(sa):
+    """benchmark/mcl.cpp:25-64 at reduced canvas: 25 particles, 90 beams over [0, pi), the same scan re-applied."""
+    N, B, rows, cols = 25, 90, 450, 800
+    free = orc.load_map("floor_plan")
+    sensor = orc.sensor_position([400.0, 400.0, np.pi], OFFSET)
+    hits = orc.fake_lidar_scan(free.astype(np.int32), sensor, 0.0, np.pi, 500.0, B)
+    ang, dist = orc.hits_to_scan(hits, sensor, 0.0, np.pi, 500.0)
+    mcl = sa.MCL(N, (cols, rows), noise=sa.capi.NOISE_INJECTED)
+    f = mcl.filter
+    sp = mcl.starting_pose()
+    assert (sp.x, sp.y, sp.theta) == (cols / 2.0, rows / 2.0, np.pi / 2)
+    state = (np.full(N, sp.x), np.full(N, sp.y), np.full(N, sp.theta), np.full(N, 1.0 / N))
+    assert_bits(f.weights(), state[3], "initial weights")
+    maps = np.full((N, rows, cols), 128, np.uint8)
+    for step in range(6):
+        z = orc.reference_normals(3 * N, tick0=50 * step + 1, tick_stride=1)
+        u = orc.reference_uniforms(N, tick=900 + step)
+        f.set_noise(z, u)
+        mcl.predict(sa.Odometry(*ODOM), ALPHAS)
+        mcl.update(list(zip(ang, dist)), 5.0, 500.0, sa.Pose(*OFFSET))
+        state, idx = run_oracle_step(state, maps, None, ang, dist, 5.0, 500.0, z, u, True, orc.ORDER_BLOCKED)
+        assert np.array_equal(f.last_indices(), idx), f"step {step}"
+        px, py, pth = f.poses()
+        assert_bits(px, state[0], "x"), assert_bits(py, state[1], "y"), assert_bits(pth, state[2], "theta")
+        assert_bits(f.weights(), state[3], "weights")
+        for p in range(N):
+            assert np.array_equal(f.map_of(p), maps[p]), f"step {step} map {p}"
+    parts = mcl.get_particles()
+    assert parts[0].weight == max(p.weight for p in parts) and np.array_equal(parts[0].map, maps[0])
+    f.close()
+
+
+@pytest.mark.parametrize("order", ["blocked", "reference"])
+def test_localization_loop(sa, order):
+    rng = np.random.default_rng(99)
+    N, B = 3000, 360
+    free = orc.load_map("floor_plan")
+    g = (free * 255).astype(np.uint8)
+    rows, cols = g.shape
+    true = [520.0, 280.0, 0.4]
+    ang, dist = orc.make_scan(free, true, OFFSET, B)
+    x, y, th = cloud(rng, N, true[0], true[1], th0=true[2])
+    o = orc.ORDER_BLOCKED if order == "blocked" else orc.ORDER_REFERENCE
+    f = sa.Filter(N, rows, cols, noise=sa.capi.NOISE_INJECTED,
+                  prefix_order=sa.capi.PREFIX_BLOCKED if order == "blocked" else sa.capi.PREFIX_REFERENCE)
+    f.set_map(g)
+    f.set_poses(x, y, th)
+    state = (x, y, th, None)
+    for step in range(5):
+        z = orc.reference_normals(3 * N, tick0=7 * step + 1, tick_stride=3)
+        u = orc.reference_uniforms(N, tick=step + 1)
+        f.set_noise(z, u)
+        f.predict(ODOM, ALPHAS)
+        f.update(ang, dist, 5.0, 500.0, OFFSET)
+        state, idx = run_oracle_step(state, None, g, ang, dist, 5.0, 500.0, z, u, False, o)
+        assert np.array_equal(f.last_indices(), idx), f"step {step}"
+        px, py, pth = f.poses()
+        assert_bits(px, state[0], "x"), assert_bits(py, state[1], "y"), assert_bits(pth, state[2], "theta")
+        assert_bits(f.weights(), state[3], "weights")
+    ap = f.average_pose()
+    oa = orc.average_pose(*state[:3])
+    assert np.allclose([ap.x, ap.y, ap.theta], oa, rtol=REL_TOL)
+    f.close()
+
+
+def test_philox_loop_is_deterministic_and_matches_host_streams(sa):
+    rng = np.random.default_rng(4)
+    N, B, seed = 2048, 90, 0x5EED0001
+    free = orc.load_map("map")
+    g = (free * 255).astype(np.uint8)
+    true = [400.0, 400.0, 0.1]
+    ang, dist = orc.make_scan(free, true, OFFSET, B)
+    x, y, th = cloud(rng, N, true[0], true[1], th0=true[2])
+    f = sa.Filter(N, *g.shape, seed=seed)
+    f.set_map(g)
+    f.set_poses(x, y, th)
+    state = (x, y, th, None)
+    for step in range(3):
+        f.predict(ODOM, ALPHAS)
+        f.update(ang, dist, 5.0, 500.0, OFFSET)
+        z = orc.philox_normals(seed, step, 0, N)
+        u = orc.philox_uniforms(seed, step, 0, N)
+        state, idx = run_oracle_step(state, None, g, ang, dist, 5.0, 500.0, z, u, False, orc.ORDER_BLOCKED)
+        assert np.array_equal(f.last_indices(), idx)
+        assert_bits(f.poses()[0], state[0], "x")
+    f.close()
+
+
+# ---- neighbours of the path: scan synthesis on the device ------------------------------------------
+def test_fake_lidar_scan_device(sa):
+    from slam_amd import capi
+
+    lib = capi.load_library()
+    free = orc.load_map("map").astype(np.uint8)
+    rows, cols = free.shape
+    rng = np.random.default_rng(8)
+    poses = np.stack([rng.uniform(50, 950, 20), rng.uniform(50, 950, 20), rng.uniform(-3, 3, 20)], 1).copy()
+    hits = np.empty((20, 90, 2))
+    capi.check(lib.slam_fake_lidar_scan(0, capi.ptr(free), rows, cols, capi.ptr(poses), 20, 0.0, 2 * np.pi, 500.0, 90,
+                                        capi.ptr(hits)))
+    for p in range(20):
+        ref = orc.fake_lidar_scan(free.astype(np.int32), poses[p], 0.0, 2 * np.pi, 500.0, 90, math=orc.DET)
+        assert_bits(hits[p], ref, f"scan {p}")
+    g = (free * 255).astype(np.uint8)
+    out = np.empty((20, 2))
+    capi.check(lib.slam_raycast_u8(0, capi.ptr(g), rows, cols, capi.ptr(poses), 20, 300.0 ** 2, 0.5, capi.ptr(out)))
+    for p in range(20):
+        assert_bits(out[p], orc.raycast(1, g, poses[p, 0], poses[p, 1], poses[p, 2], 300.0 ** 2, 0.5, math=orc.DET), "raycast")
+
+
+# ---- error behaviour ------------------------------------------------------------------------------------
+def test_errors_are_reported_not_swallowed(sa):
+    with pytest.raises(sa.SlamError):
+        sa.Filter(0, 10, 10)
+    f = sa.Filter(8, 10, 10)
+    with pytest.raises(sa.SlamError):
+        f.update_weights([0.0], [1.0], 5.0, 10.0)          # no map yet
+    f.set_map(np.full((10, 10), 255, np.uint8))
+    with pytest.raises(sa.SlamError):
+        f.set_poses([np.nan] * 8, [0.0] * 8, [0.0] * 8)     # SURVEY.md §7 hard part 9: finite poses only
+    with pytest.raises(sa.SlamError):
+        f.update_weights([0.0], [1.0], 0.0, 10.0)           # stddev must be positive
+    with pytest.raises(sa.SlamError):
+        f.set_map(np.zeros((5, 5), np.uint8))               # size differs
+    with pytest.raises(sa.SlamError):
+        f.map_of(0)                                         # localization mode holds no per-particle maps
+    f.close()
+
+
+# ---- BASELINE.json config 2 at full size: size-independent properties ------------------------------
+def test_full_size_config2_properties(sa):
+    rng = np.random.default_rng(2)
+    N, B = 100_000, 360
+    free = orc.load_map("floor_plan")
+    g = (free * 255).astype(np.uint8)
+    rows, cols = g.shape
+    true = [520.0, 280.0, 0.4]
+    ang, dist = orc.make_scan(free, true, OFFSET, B)
+    x, y, th = cloud(rng, N, true[0], true[1], th0=true[2])
+    fast = sa.Filter(N, rows, cols, seed=1)
+    walk = sa.Filter(N, rows, cols, seed=1, raycaster=sa.capi.RAYCAST_WALK)
+    for f in (fast, walk):
+        f.set_map(g)
+        f.set_poses(x, y, th)
+        f.predict(ODOM, ALPHAS)
+        f.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+    wf, ww = fast.weights(), walk.weights()
+    assert_bits(wf, ww, "clearance-skipping vs cell-by-cell walk")     # two independent device algorithms agree
+    sub = rng.choice(N, 400, replace=False)                            # oracle on a sample the CPU finishes in seconds
+    px, py, pth = fast.poses()
+    ow, _ = orc.update_weights(px[sub], py[sub], pth[sub], g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET)
+    assert_bits(wf[sub], ow, "weights vs oracle sample")
+    st = walk.stats()
+    assert st["cells_written"] == 0 and 10 * N * B < st["cells_read"] <= 502 * N * B
+    fast.update_weights(ang, dist, 5.0, 500.0, OFFSET)                 # idempotent: read-only map
+    assert_bits(fast.weights(), wf, "idempotence")
+    fast.resample()
+    idx = fast.last_indices()
+    P, s = fast.prefix()
+    oidx, oP, _ = orc.resample(wf, orc.philox_uniforms(1, 0, 0, N), orc.ORDER_BLOCKED)
+    assert_bits(P, oP, "running sums")
+    assert np.array_equal(idx, oidx)
+    nw = fast.weights()
+    assert np.all(np.diff(nw) <= 0) and np.array_equal(np.sort(wf[idx])[::-1], nw)
+    fast.close(), walk.close()
+
+
+# ---- sharded resampling: any number of shards gives the single-handle result ------------------------
+@pytest.mark.parametrize("shards", [2, 4])
+def test_sharded_filter_matches_single_handle(sa, shards):
+    import torch
+
+    from slam_amd.dist import HipShard, ShardedFilter
+
+    rng = np.random.default_rng(31)
+    N, B, seed = 4096, 90, 0xC0FFEE
+    free = orc.load_map("floor_plan")
+    g = (free * 255).astype(np.uint8)
+    rows, cols = g.shape
+    true = [520.0, 280.0, 0.4]
+    ang, dist = orc.make_scan(free, true, OFFSET, B)
+    x, y, th = cloud(rng, N, true[0], true[1], th0=true[2])
+    single = sa.Filter(N, rows, cols, seed=seed, sort=sa.capi.SORT_NONE)
+    single.set_map(g)
+    single.set_poses(x, y, th)
+    n_loc = N // shards
+    backs = [HipShard(n_loc, rows, cols, r, shards, 0, seed) for r in range(shards)]
+    for r, b in enumerate(backs):
+        b.set_map(g)
+        b.f.set_poses(x[r * n_loc:(r + 1) * n_loc], y[r * n_loc:(r + 1) * n_loc], th[r * n_loc:(r + 1) * n_loc])
+    state = (x, y, th)
+    for step in range(3):
+        single.predict(ODOM, ALPHAS)
+        single.update(ang, dist, 5.0, 500.0, OFFSET)
+        for b in backs:
+            b.predict(ODOM, ALPHAS)
+            b.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+        gathered = torch.cat([b.packed_state() for b in backs])      # what all_gather_into_tensor produces
+        torch.cuda.synchronize()
+        for b in backs:
+            b.shard_resample(gathered, shards)
+        # oracle, unsorted order
+        ox, oy, oth = orc.predict(*state, ODOM, ALPHAS, orc.philox_normals(seed, step, 0, N), math=orc.DET)
+        ow, _ = orc.update_weights(ox, oy, oth, g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET)
+        idx, _, _ = orc.resample(ow, orc.philox_uniforms(seed, step, 0, N), orc.ORDER_BLOCKED)
+        state = (ox[idx], oy[idx], oth[idx])
+        assert np.array_equal(single.last_indices(), idx)
+        assert np.array_equal(np.concatenate([b.f.last_indices() for b in backs]), idx)
+        for q in range(3):
+            assert_bits(single.poses()[q], state[q], "single handle")
+            assert_bits(np.concatenate([b.f.poses()[q] for b in backs]), state[q], f"{shards} shards")
+        assert_bits(np.concatenate([b.f.weights() for b in backs]), ow[idx], "weights")
+    # the driver class itself with world = 1
+    sf = ShardedFilter(HipShard(N, rows, cols, 0, 1, 0, seed), world=1)
+    sf.b.set_map(g)
+    sf.b.f.set_poses(x, y, th)
+    sf.predict(ODOM, ALPHAS)
+    sf.update(ang, dist, 5.0, 500.0, OFFSET)
+    ox, oy, oth = orc.predict(x, y, th, ODOM, ALPHAS, orc.philox_normals(seed, 0, 0, N), math=orc.DET)
+    ow, _ = orc.update_weights(ox, oy, oth, g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET)
+    idx, _, _ = orc.resample(ow, orc.philox_uniforms(seed, 0, 0, N), orc.ORDER_BLOCKED)
+    assert_bits(sf.b.f.poses()[0], ox[idx], "ShardedFilter world=1")
