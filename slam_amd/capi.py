@@ -103,6 +103,13 @@ def load_library(path=None):
             f"{p} not found: build it with `python -m slam_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback."
         )
+    # PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one process
+    # leave the second one without GPUs.  Importing torch first makes this library bind to the
+    # runtime torch already loaded (same SONAME), so torch streams/RCCL and our kernels share it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(p)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
