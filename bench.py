@@ -2,7 +2,9 @@
 
 One "step" = MCL::predict + MCL::update (weights from raycast + beam likelihood, running sum,
 multinomial selection, sort/gather) over the resident particle set, as in the reference's timed
-loop (benchmark/mcl.cpp:58-64: the same scan is re-applied every iteration).
+loop (benchmark/mcl.cpp:58-64), with its odometry and alphas.  Unlike that loop, which re-applies
+one stale scan while the robot turns 2.5 rad per step, the scan is refreshed from the (noise-free)
+true pose every step as apps/grid_slam.cpp:142-168 does, so the filter tracks instead of collapsing.
 
 Workload at N = 1: BASELINE.json configs[1] — localization on assets/floor_plan.png (1297 x 599),
 100k particles x 360 beams, max range 500, sigma 5, scanner offset {0,30,0}.  N > 1 is weak scaling:
@@ -37,22 +39,45 @@ def load_free_grid(name):
     return np.unpackbits(z[name + "_bits"])[: int(sh[0]) * int(sh[1])].reshape(int(sh[0]), int(sh[1]))
 
 
-def synth_scan(sa, free, device, n_beams):
-    """apps/grid_slam.cpp:144-166 with the device FakeLidar: sensor pose -> hits -> (angle, dist)."""
+def true_trajectory(n_steps):
+    """Noise-free robot motion, as benchmark/mcl.cpp:62 moves real_position (default alphas = 0):
+    pose k is where the robot is when scan k is taken, i.e. after k+1 odometry steps."""
+    x, y, th = TRUE_POSE
+    out = []
+    for _ in range(n_steps):
+        r1, t, r2 = ODOM
+        x, y = x + t * np.cos(th + r1), y + t * np.sin(th + r1)
+        th = np.fmod(th + r1 + r2, 2 * np.pi)
+        if th > np.pi:
+            th -= 2 * np.pi
+        out.append((x, y, th))
+    return out
+
+
+def synth_scans(sa, free, device, n_beams, poses):
+    """apps/grid_slam.cpp:144-166 with the device FakeLidar: one scan per robot pose ->
+    list of (angles, dists).  The scan is refreshed every step, as the app does (the reference's
+    own benchmark re-applies one stale scan while the robot turns 2.5 rad per step)."""
     from slam_amd import capi
 
     lib = capi.load_library()
-    sensor = sa.MCL.sensor_position(sa.Pose(*TRUE_POSE), sa.Pose(*OFFSET))
-    pose = np.array([[sensor.x, sensor.y, sensor.theta]])
-    hits = np.empty((n_beams, 2))
+    sensors = [sa.MCL.sensor_position(sa.Pose(*p), sa.Pose(*OFFSET)) for p in poses]
+    sp = np.array([[s.x, s.y, s.theta] for s in sensors])
+    hits = np.empty((len(poses), n_beams, 2))
     m01 = np.ascontiguousarray(free, dtype=np.uint8)
-    capi.check(lib.slam_fake_lidar_scan(device, capi.ptr(m01), m01.shape[0], m01.shape[1], capi.ptr(pose), 1, 0.0,
+    capi.check(lib.slam_fake_lidar_scan(device, capi.ptr(m01), m01.shape[0], m01.shape[1], capi.ptr(sp), len(poses), 0.0,
                                         2 * np.pi, MAX_DIST, n_beams, capi.ptr(hits)))
     step = 2 * np.pi / n_beams
     ang = np.arange(n_beams) * step - np.pi
-    d = np.sqrt((hits[:, 1] - sensor.y) ** 2 + (hits[:, 0] - sensor.x) ** 2)
-    dist = np.where(hits[:, 0] != -1, d, MAX_DIST)
-    return ang, dist
+    scans = []
+    for k in range(len(poses)):
+        d = np.sqrt((hits[k, :, 1] - sp[k, 1]) ** 2 + (hits[k, :, 0] - sp[k, 0]) ** 2)
+        scans.append((ang, np.where(hits[k, :, 0] != -1, d, MAX_DIST)))
+    return scans
+
+
+def synth_scan(sa, free, device, n_beams):
+    return synth_scans(sa, free, device, n_beams, [TRUE_POSE])[0]
 
 
 def cpu_baseline(free, ang, dist, n_beams, budget_s=12.0):
@@ -119,20 +144,27 @@ def main():
     grid = (free * 255).astype(np.uint8)
     rows, cols = grid.shape
     n_loc, B = args.particles, args.beams
-    ang, dscan = synth_scan(sa, free, local_rank, B)
+    scans = synth_scans(sa, free, local_rank, B, true_trajectory(args.warmup + args.steps))
+    ang, dscan = scans[0]
+    step_no = [0]
 
     if world == 1:
         f = sa.Filter(n_loc, rows, cols, device=local_rank, seed=SEED, stream=stream, async_launch=True)
         f.set_map(grid)
         step_predict = lambda: f.predict(ODOM, ALPHAS)
-        step_update = lambda: f.update(ang, dscan, STDDEV, MAX_DIST, OFFSET)
+        upd = lambda a, d: f.update(a, d, STDDEV, MAX_DIST, OFFSET)
     else:
         shard = HipShard(n_loc, rows, cols, rank, world, local_rank, SEED, stream=stream, async_launch=True)
         shard.set_map(grid)
         sf = ShardedFilter(shard, world=world)
         f = shard.f
         step_predict = lambda: sf.predict(ODOM, ALPHAS)
-        step_update = lambda: sf.update(ang, dscan, STDDEV, MAX_DIST, OFFSET)
+        upd = lambda a, d: sf.update(a, d, STDDEV, MAX_DIST, OFFSET)
+
+    def step_update():
+        a, d = scans[step_no[0]]
+        step_no[0] += 1
+        upd(a, d)
     f.seed_gaussian(TRUE_POSE, [25.0, 25.0, 0.2])  # Gaussian cloud around the true pose
 
     def barrier():
@@ -145,7 +177,8 @@ def main():
         wk = sa.Filter(n_loc, rows, cols, device=local_rank, raycaster=capi.RAYCAST_WALK, sort=capi.SORT_NONE)
         wk.set_map(grid)
         wk.set_poses(x, y, th)
-        wk.update_weights(ang, dscan, STDDEV, MAX_DIST, OFFSET)
+        a_, d_ = scans[min(step_no[0], len(scans) - 1)]
+        wk.update_weights(a_, d_, STDDEV, MAX_DIST, OFFSET)
         s = wk.stats()["cells_read"] / float(n_loc * B)
         wk.close()
         return s

@@ -37,7 +37,13 @@ enum { SLAM_NOISE_PHILOX = 0, SLAM_NOISE_INJECTED = 1 };
 enum { SLAM_PREFIX_BLOCKED = 0, SLAM_PREFIX_REFERENCE = 1 };
 enum { SLAM_RESAMPLE_MULTINOMIAL = 0, SLAM_RESAMPLE_SYSTEMATIC = 1 };
 enum { SLAM_SORT_FULL = 0, SLAM_SORT_NONE = 1 };
-enum { SLAM_RAYCAST_FAST = 0, SLAM_RAYCAST_WALK = 1 };
+enum
+{
+    SLAM_RAYCAST_FAST = 0,                /* clearance-skipping search; kernel shape chosen by N */
+    SLAM_RAYCAST_WALK = 1,                /* literal cell-by-cell walk (counts cells) */
+    SLAM_RAYCAST_FAST_BEAM_LANES = 2,     /* force: one wavefront per particle, lanes over beams */
+    SLAM_RAYCAST_FAST_PARTICLE_LANES = 3  /* force: lane = particle, work item = (64 particles, beam segment) */
+};
 
 /* Construction parameters.  Zero-initialise, set struct_size = sizeof(slam_mcl_params), fill in.
  * Replaces the constructor arguments of slam::MCL (slam/mcl.h:15, slam/mcl.cpp:16-39). */

@@ -13,7 +13,7 @@ NOISE_PHILOX, NOISE_INJECTED = 0, 1
 PREFIX_BLOCKED, PREFIX_REFERENCE = 0, 1
 RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
 SORT_FULL, SORT_NONE = 0, 1
-RAYCAST_FAST, RAYCAST_WALK = 0, 1
+RAYCAST_FAST, RAYCAST_WALK, RAYCAST_FAST_BEAM_LANES, RAYCAST_FAST_PARTICLE_LANES = 0, 1, 2, 3
 
 
 class SlamError(RuntimeError):

@@ -64,3 +64,14 @@ inline void slam_build_clearance(const uint8_t* map, int rows, int cols, uint8_t
     }
     for (size_t c = 0; c < n; ++c) E[c] = (uint8_t)std::min<uint16_t>(d[c], 255);
 }
+
+// Padded layout read by the kernels: (rows+4) x (cols+4) bytes, cell (i,j) at (i+2)*(cols+4)+(j+2),
+// frame = 0 ("occupied or outside": the hot loop stops there and the caller tells the two apart).
+inline void slam_build_clearance_padded(const uint8_t* map, int rows, int cols, uint8_t* Ep)
+{
+    std::vector<uint8_t> E((size_t)rows * cols);
+    slam_build_clearance(map, rows, cols, E.data());
+    const size_t pitch = (size_t)cols + 4;
+    std::fill(Ep, Ep + (size_t)(rows + 4) * pitch, (uint8_t)0);
+    for (int i = 0; i < rows; ++i) std::copy(E.begin() + (size_t)i * cols, E.begin() + (size_t)(i + 1) * cols, Ep + (size_t)(i + 2) * pitch + 2);
+}

@@ -81,33 +81,26 @@ DM_HD double dm_fmod_pos(double x, double y)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Argument reduction by pi/2 (three-stage Cody-Waite, pi/2 carried to 33+33+33+53 bits).
-// Returns n (quadrant count) and y0 + y1 = x - n*pi/2.
-DM_HD int dm_rem_pio2(double x, double* y0, double* y1)
+// Argument reduction by pi/2 (Cody-Waite, pi/2 carried to 33+33+53 bits, a third 33-bit piece when
+// the argument is within 2^-49 (relative) of a multiple of pi/2).  Returns n (quadrant count) and
+// y0 + y1 = |x| - n*pi/2 for the ABSOLUTE value of x; the caller applies the sign.  Written without
+// data-dependent branches on the common path (GPU lanes stay converged).
+DM_HD int dm_rem_pio2_abs(double t, double* y0, double* y1)
 {
     const double invpio2 = dm_from_bits(0x3FE45F306DC9C883ull);  // 6.36619772367581382433e-01
     const double pio2_1 = dm_from_bits(0x3FF921FB54400000ull);   // first 33 bits of pi/2
-    const double pio2_1t = dm_from_bits(0x3DD0B4611A626331ull);  // pi/2 - pio2_1
     const double pio2_2 = dm_from_bits(0x3DD0B4611A600000ull);   // second 33 bits
     const double pio2_2t = dm_from_bits(0x3BA3198A2E037073ull);  // pi/2 - (pio2_1+pio2_2)
     const double pio2_3 = dm_from_bits(0x3BA3198A2E000000ull);   // third 33 bits
     const double pio2_3t = dm_from_bits(0x397B839A252049C1ull);  // pi/2 - (pio2_1+pio2_2+pio2_3)
 
-    const uint32_t ix = dm_hi(x) & 0x7fffffffu;
-    if (ix <= 0x3fe921fbu)
-    {  // |x| <= pi/4
-        *y0 = x;
-        *y1 = 0.0;
-        return 0;
-    }
-    double t = dm_fabs(x);
-    if (ix >= 0x41300000u)
+    if (!(t < 1048576.0))
     {
         // |x| >= 2^20: outside the range the filter produces (normalize_angle keeps headings in
         // (-2pi, pi]).  Deterministic but reduced-accuracy fallback: exact fmod by the double 2*pi.
-        if (ix >= 0x7ff00000u)
+        if (!(t < dm_from_bits(0x7FF0000000000000ull)))
         {
-            *y0 = x - x;
+            *y0 = t - t;  // inf/nan -> nan
             *y1 = 0.0;
             return 0;
         }
@@ -115,37 +108,25 @@ DM_HD int dm_rem_pio2(double x, double* y0, double* y1)
     }
     const int n = (int)(t * invpio2 + 0.5);
     const double fn = (double)n;
-    double r = t - fn * pio2_1;  // fn*pio2_1 is exact (<= 21 + 33 bits)
-    double w = fn * pio2_1t;
-    const int j = (int)((dm_bits(t) >> 52) & 0x7ff);
+    // two exact 33-bit pieces (fn*pio2_1 and fn*pio2_2 are exact products), then the tail
+    double r = (t - fn * pio2_1);
+    double w = fn * pio2_2;
+    double t2 = r;
+    r = t2 - w;
+    w = fn * pio2_2t - ((t2 - r) - w);
     double a = r - w;
-    int i = j - (int)((dm_bits(a) >> 52) & 0x7ff);
-    if (i > 16)
-    {  // 2nd stage, good to 118 bits
-        double t2 = r;
-        w = fn * pio2_2;
+    const int j = (int)((dm_bits(t) >> 52) & 0x7ff);
+    const int i = j - (int)((dm_bits(a) >> 52) & 0x7ff);
+    if (i > 49)
+    {  // heavy cancellation: third piece, 151 bits of pi/2
+        t2 = r;
+        w = fn * pio2_3;
         r = t2 - w;
-        w = fn * pio2_2t - ((t2 - r) - w);
+        w = fn * pio2_3t - ((t2 - r) - w);
         a = r - w;
-        i = j - (int)((dm_bits(a) >> 52) & 0x7ff);
-        if (i > 49)
-        {  // 3rd stage, 151 bits
-            t2 = r;
-            w = fn * pio2_3;
-            r = t2 - w;
-            w = fn * pio2_3t - ((t2 - r) - w);
-            a = r - w;
-        }
-    }
-    const double b = (r - a) - w;
-    if (dm_bits(x) >> 63)
-    {
-        *y0 = -a;
-        *y1 = -b;
-        return -n;
     }
     *y0 = a;
-    *y1 = b;
+    *y1 = (r - a) - w;
     return n;
 }
 
@@ -185,28 +166,17 @@ DM_HD double dm_kcos(double x, double y)
 DM_HD void dm_sincos(double x, double* s, double* c)
 {
     double y0, y1;
-    const int n = dm_rem_pio2(x, &y0, &y1);
+    const int n = dm_rem_pio2_abs(dm_fabs(x), &y0, &y1);
     const double sn = dm_ksin(y0, y1);
     const double cs = dm_kcos(y0, y1);
-    switch (n & 3)
-    {
-        case 0:
-            *s = sn;
-            *c = cs;
-            break;
-        case 1:
-            *s = cs;
-            *c = -sn;
-            break;
-        case 2:
-            *s = -sn;
-            *c = -cs;
-            break;
-        default:
-            *s = -cs;
-            *c = sn;
-            break;
-    }
+    // quadrant of |x|: (sin, cos) = (sn, cs), (cs, -sn), (-sn, -cs), (-cs, sn)
+    double ss = (n & 1) ? cs : sn;
+    double cc = (n & 1) ? sn : cs;
+    if (n & 2) ss = -ss;
+    if ((n + 1) & 2) cc = -cc;
+    // sin is odd, cos is even
+    *s = (dm_bits(x) >> 63) ? -ss : ss;
+    *c = cc;
 }
 
 DM_HD double dm_sin(double x)

@@ -72,7 +72,7 @@ struct WeightArgs
     size_t map_stride;     // S mode: bytes between particle maps
     int rows, cols, B;
     const double *angles, *z2, *z;  // per beam: angle, dist^2, sqrt(dist^2)
-    double zmax2, zmax, stddev, norm;
+    double zmax2, zmax, stddev, norm, log_eps;
     double sd, stheta, srot;        // scanner displacement (slam/mcl.cpp:80-86) and rotation
     int k_safe, max_iter;
     double* w;
@@ -80,6 +80,11 @@ struct WeightArgs
     int32_t* hit_cell;  // optional n*B
     unsigned long long* stats;  // optional 3 counters
     const uint8_t* luts;        // 512 bytes: free table then occupied table
+    // particle-lane decomposition (k_rays_pl / k_sum_lw)
+    double* lw;                 // scratch: per (particle block, beam, lane) log-likelihoods
+    int64_t p_first;            // first particle of this launch
+    int64_t npblocks;           // 64-particle blocks in this launch
+    int nseg, seg_beams;        // beams are cut into nseg segments of seg_beams
 };
 
 // K2a.  VARIANT 0: ray_fast_L on the clearance grid.  VARIANT 1: literal walk on the raw map
@@ -110,11 +115,11 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
             dm_sincos(theta, &s, &c);
             slam_ray_result r;
             if (VARIANT == 0)
-                ray_fast_L(a.grid, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr);
+                ray_fast_L(a.grid, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr);
             else
                 ray_walk<false, true>(a.grid, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, nullptr, nullptr,
                                       a.max_iter, &r, &st);
-            lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm);
+            lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
             if (a.hit_xy)
             {
                 const size_t o = (size_t)p * a.B + b;
@@ -133,6 +138,70 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
         atomicAdd(&a.stats[1], st.cells_written);
         atomicAdd(&a.stats[2], st.steps);
     }
+}
+
+// K2a, particle-lane form (large N).  Lane = particle, so the 64 rays a wavefront walks together
+// share the beam index: they are near-parallel rays from nearby origins (after a resample+sort,
+// often copies of one particle), which keeps the data-dependent trip count of ray_fast_L uniform
+// across lanes and makes the scan entries wave-uniform (scalar loads).  A work item is
+// (64-particle block, beam segment); the per-beam log-likelihoods go to a scratch slab
+// lw[block][beam][lane] (coalesced 512-byte stores) and k_sum_lw adds them per particle in beam
+// order, reproducing the sequential rounding of slam/mcl.cpp:69-74.
+template <int MIN_WAVES>
+__global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t pb = item / a.nseg;
+    if (pb >= a.npblocks) return;  // whole wavefront
+    const int seg = (int)(item - pb * a.nseg);
+    int64_t p = a.p_first + pb * 64 + lane;
+    if (p >= a.n) p = a.n - 1;  // padding lanes repeat the last particle; their values are never summed
+    const double px = a.x[p], py = a.y[p], pth = a.th[p];
+    double s0, c0;
+    dm_sincos(pth + a.stheta, &s0, &c0);
+    const double sx = px + c0 * a.sd;
+    const double sy = py + s0 * a.sd;
+    double* slab = a.lw + (size_t)pb * (size_t)a.B * 64 + lane;
+    const int b0 = seg * a.seg_beams;
+    const int b1 = (b0 + a.seg_beams) < a.B ? (b0 + a.seg_beams) : a.B;
+    for (int b = b0; b < b1; ++b)
+    {
+        const double theta = pth + a.angles[b] + a.srot;
+        double s, c;
+        dm_sincos(theta, &s, &c);
+        slam_ray_result r;
+        ray_fast_L(a.grid, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr);
+        slab[(size_t)b * 64] = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
+        if (a.hit_xy)
+        {
+            const size_t o = (size_t)p * a.B + b;
+            a.hit_xy[2 * o] = r.hx;
+            a.hit_xy[2 * o + 1] = r.hy;
+            a.hit_cell[o] = r.hcell;
+        }
+    }
+}
+
+// weight = exp(sum_b lw[b]) with the sum taken in beam order (slam/mcl.cpp:67-75).
+__global__ void __launch_bounds__(256) k_sum_lw(WeightArgs a)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // particle within this launch
+    const int64_t p = a.p_first + q;
+    if (q >= a.npblocks * 64 || p >= a.n) return;
+    const double* slab = a.lw + (size_t)(q >> 6) * (size_t)a.B * 64 + (q & 63);
+    double acc = 0.0;
+    int b = 0;
+    for (; b + 8 <= a.B; b += 8)
+    {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(b + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < a.B; ++b) acc += slab[(size_t)b * 64];
+    a.w[p] = dm_exp(acc);
 }
 
 // K2b, first form: one thread per particle, beams and cells strictly in the reference's order.
@@ -158,7 +227,7 @@ __global__ void __launch_bounds__(64) k_weights_S(WeightArgs a)
         dm_sincos(theta, &s, &c);
         slam_ray_result r;
         ray_walk<true, true>(map, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, luts, luts + 256, a.max_iter, &r, &st);
-        acc += slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm);
+        acc += slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
         if (a.hit_xy)
         {
             const size_t o = (size_t)p * a.B + b;

@@ -9,14 +9,14 @@
 //                (a) exact m-step jumps of the accumulated position and (b) a clearance grid.
 //
 // (a) Exact jumps.  While x stays inside one binade (fixed exponent, ulp u) every x_k is a multiple
-// of u and fl(x_k + dx) = x_k + inc with a constant inc = dx rounded to the u grid.  A tie
-// (dx an odd multiple of u/2) breaks constancy only for the first add inside the binade: after
-// it x/u is even and round-half-even then yields a constant increment as well.  So after two
-// real adds inside a binade, inc = x_k - x_{k-1} (exact) and x_{k+m} = fma(m, inc, x_k) exactly,
-// for as long as the exact sums stay inside the binade (axis_rem() bounds that count with margin).
-// Binade crossings and the first two steps of a ray use real adds.
+// of u and fl(x_k + dx) = x_k + inc with the constant inc = dx rounded to the u grid (unless dx is
+// an exact tie, an odd multiple of u/2).  Hence x_{k+m} = fma(m, inc, x_k) exactly, for as long as
+// the exact sums stay inside the binade; slam_axis_setup() derives inc and that count (with
+// margin).  The add that crosses a binade edge, the few adds inside the margin before it, ties and
+// |x| < 4 use real adds.
 //
-// (b) Clearance grid E (uint8 per cell, built by the library when the map is set): E = 0 for an
+// (b) Clearance grid E (uint8 per cell, built by the library when the map is set, stored with a
+// two-cell frame of zeros, see clearance.h): E = 0 for an
 // occupied cell (< 128), otherwise min(255, Chebyshev distance to the nearest occupied or
 // out-of-grid cell) >= 1.  From a sample inside a cell with E >= 1, all cells within Chebyshev
 // distance E-1 are free and in bounds, and a step moves at most max(|dx|,|dy|) per axis, so the
@@ -32,6 +32,13 @@ DM_HD int slam_f2i(double v) { return (int)v; }  // v_cvt_i32_f64: truncates, sa
 #else
 // x86 cvttsd2si semantics for out-of-range input (the reference's host behaviour), without UB.
 DM_HD int slam_f2i(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (-2147483647 - 1); }
+#endif
+
+// approximate 1/x (1 ulp on the device): used only where a safety factor absorbs the error
+#if defined(__HIP_DEVICE_COMPILE__)
+DM_HD float slam_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+DM_HD float slam_rcpf(float x) { return 1.0f / x; }
 #endif
 
 DM_HD void slam_cell_of(int rows, double x, double y, int* i, int* j)
@@ -120,113 +127,224 @@ DM_HD void ray_walk(uint8_t* map, int rows, int cols, double sx, double sy, doub
 
 // ------------------------------------------------------------------------------------------------
 // Exact-jump machinery.
+//
+// One axis of the accumulated position.  While v stays inside one binade [2^E, 2^(E+1)) with ulp u,
+// fl(v + d) = v + inc for the constant inc = d rounded to the u grid, PROVIDED d is not an exact
+// tie (an odd multiple of u/2; then round-half-even makes the increment depend on the parity of
+// v/u).  slam_axis_setup computes inc with the add-and-subtract-a-big-constant rounding trick and
+// the number `rem` of further adds that provably stay inside the binade (with margin).  Ties,
+// |v| < 4, zeros, subnormals and non-finite values get rem = 0: such a stretch is walked with real
+// adds, which are always right.
 struct slam_axis
 {
-    double v;    // current accumulated coordinate
-    double inc;  // steady-state increment (valid while rem > 0)
-    int rem;     // jumps that are still provably exact
-    int cnt;     // consecutive real adds that stayed inside the current binade
+    double v;    // accumulated coordinate of the current sample
+    double inc;  // constant increment inside the current binade (valid while rem > 0)
+    int rem;     // adds that can still be replaced by fma(m, inc, v)
 };
 
-DM_HD int slam_axis_rem(double v, double inc)
+DM_HD void slam_axis_setup(slam_axis* a, double d)
 {
-    if (inc == 0.0) return 1 << 20;  // fl(v + d) == v forever
-    const uint64_t b = dm_bits(v);
+    const uint64_t b = dm_bits(a->v);
     const int e = (int)((b >> 52) & 0x7ff);
-    const double ai = dm_fabs(inc);
-    if (e == 0 || e == 0x7ff || ai < 1e-30) return 0;
-    const double a = dm_fabs(v);
-    const double lo = dm_from_bits((uint64_t)e << 52);
-    const bool grow = (inc > 0.0) == ((b >> 63) == 0);
-    const double num = grow ? (lo + lo) - a : a - lo;  // exact
-    float q = (float)num / (float)ai;
-    q = q < 1.0e6f ? q : 1.0e6f;
-    const int r = (int)(q * 0.999f) - 2;  // margin: float rounding + one full step from the edge
-    return r < 0 ? 0 : r;
-}
-
-DM_HD void slam_axis_real_step(slam_axis* s, double d)
-{
-    const double nv = s->v + d;
-    const bool same = (dm_bits(nv) >> 52) == (dm_bits(s->v) >> 52);
-    s->cnt = same ? s->cnt + 1 : 0;
-    s->inc = nv - s->v;  // exact when same binade
-    s->v = nv;
-    s->rem = (s->cnt >= 2) ? slam_axis_rem(nv, s->inc) : 0;
-}
-
-DM_HD void slam_axis_step(slam_axis* s, double d, int t)
-{
-    if (s->rem >= t)
+    a->rem = 0;
+    a->inc = 0.0;
+    if (e < 0x401 || e > 0x433) return;  // |v| < 4 or |v| >= 2^53 (or inf/nan): real adds only
+    // C = 1.5 * 2^E: d + C lies in [2^E, 2^(E+1)) for |d| <= 1, so fl(d + C) is d rounded to the u grid
+    const double C = dm_from_bits(((uint64_t)e << 52) | 0x0008000000000000ull);
+    const double r = (d + C) - C;                                   // exact difference
+    const double t = dm_fabs(d - r);                                // exact residual, <= u/2
+    const double half_ulp = dm_from_bits((uint64_t)(e - 53) << 52);  // u/2 = 2^(E-53)
+    if (!(dm_fabs(d) <= 1.0) || t == half_ulp) return;              // tie: no constant increment
+    a->inc = r;
+    if (r == 0.0)
     {
-        s->v = dm_fma((double)t, s->inc, s->v);  // exact: multiple of ulp inside the binade
-        s->rem -= t;
+        a->rem = 1 << 20;  // fl(v + d) == v for every add
+        return;
     }
-    else
-        slam_axis_real_step(s, d);  // only reached with t == 1
+    const double av = dm_fabs(a->v);
+    const double lo = dm_from_bits((uint64_t)e << 52);
+    const bool grow = (r > 0.0) == ((b >> 63) == 0);
+    const double num = grow ? (lo + lo) - av : av - lo;  // exact distance to the binade edge
+    float q = (float)num * slam_rcpf((float)dm_fabs(r));  // |r| >= u >= 2^-50: no float underflow
+    q = q < 1.0e6f ? q : 1.0e6f;
+    // adds that land strictly inside the binade: ceil(num/|r|) - 1; the factor covers the float
+    // rounding of q (relative 3e-7) and makes an exact integer quotient round down
+    a->rem = (int)(q * 0.99999f);
 }
 
+// One real add; re-derives inc/rem when the add left the binade.
+DM_HD void slam_axis_real_add(slam_axis* a, double d)
+{
+    const double nv = a->v + d;
+    const bool crossed = (dm_bits(nv) >> 52) != (dm_bits(a->v) >> 52);
+    a->v = nv;
+    if (crossed)
+        slam_axis_setup(a, d);
+    else if (a->rem > 0)
+        a->rem -= 1;
+}
+
+// Advance both axes by m samples (m >= 1), exactly as m real adds would.
 DM_HD void slam_advance(slam_axis* X, slam_axis* Y, double dx, double dy, int m)
 {
-    while (m > 0)
+    for (;;)
     {
-        int r = X->rem < Y->rem ? X->rem : Y->rem;
-        if (r < 1) r = 1;
-        const int t = m < r ? m : r;
-        slam_axis_step(X, dx, t);
-        slam_axis_step(Y, dy, t);
-        m -= t;
+        const int r = X->rem < Y->rem ? X->rem : Y->rem;
+        if (m <= r)
+        {  // hot path: one fma per axis; v + m*inc is a multiple of ulp inside the binade -> exact
+            const double tf = (double)m;
+            X->v = dm_fma(tf, X->inc, X->v);
+            Y->v = dm_fma(tf, Y->inc, Y->v);
+            X->rem -= m;
+            Y->rem -= m;
+            return;
+        }
+        if (r > 0)
+        {
+            const double tf = (double)r;
+            X->v = dm_fma(tf, X->inc, X->v);
+            Y->v = dm_fma(tf, Y->inc, Y->v);
+            X->rem -= r;
+            Y->rem -= r;
+            m -= r;
+        }
+        slam_axis_real_add(X, dx);
+        slam_axis_real_add(Y, dy);
+        if (--m == 0) return;
     }
 }
 
 // Localization-mode hit search: identical result to ray_walk<false> on the uint8 map the
-// clearance grid `E` was built from.  k_safe = max(0, floor(zmax) - 1): for samples k <= k_safe
-// the distance test of slam/raycast.cpp:216 cannot fire (k^2 <= zmax^2 - 2 zmax + 1).
-DM_HD void ray_fast_L(const uint8_t* E, int rows, int cols, double sx, double sy, double dx, double dy, double zmax2,
-                      int k_safe, slam_ray_result* res, unsigned* reads)
+// clearance grid was built from.
+//
+// Ep is the PADDED clearance grid: (rows+4) x pitch bytes, pitch = cols+4, cell (i,j) at
+// Ep[(i+2)*pitch + (j+2)], the two-cell frame filled with 0.  A jump chosen from clearance e lands
+// at most e cells (Chebyshev) from an in-bounds cell whose nearest outside cell is >= e away, so a
+// landing sample is either in bounds or in the first ring outside; the frame lets the hot loop read
+// it without a bounds test, and "e == 0" means "hit or left the grid" (told apart afterwards).
+// k_safe = max(0, floor(zmax) - 1): for samples k <= k_safe the distance test of
+// slam/raycast.cpp:216 cannot fire (k^2 <= zmax^2 - 2 zmax + 1).
+DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
+                      double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
 {
     res->hx = -1.0;
     res->hy = -1.0;
     res->hcell = -1;
-    slam_axis X = {sx, 0.0, 0, 0}, Y = {sy, 0.0, 0, 0};
-    int ci0, cj0;
-    slam_cell_of(rows, sx, sy, &ci0, &cj0);
+    const int org = 2 * pitch + 2;
     // accumulated rounding stays far below the distance margin only for moderate coordinates;
     // anything farther out starts (and stays) outside every supported grid: literal loop only.
-    if (!(dm_fabs(sx) < 1048576.0 && dm_fabs(sy) < 1048576.0)) k_safe = 0;
-    const float adx = (float)dm_fabs(dx), ady = (float)dm_fabs(dy);
-    const float scale = 0.9999f / (adx > ady ? adx : ady);
-    int k = 0;
+    int left = (dm_fabs(sx) < 1048576.0 && dm_fabs(sy) < 1048576.0) ? k_safe : 0;
+    double x = sx, y = sy;
     int i, j;
-    for (;;)
+    slam_cell_of(rows, x, y, &i, &j);
+    // sample 0 (the start cell) is never tested (slam/raycast.cpp:153-157); its clearance still
+    // tells how far the first jump may go.
+    unsigned e = 0;
+    if (slam_in_bounds(rows, cols, i, j))
     {
-        slam_cell_of(rows, X.v, Y.v, &i, &j);
-        const bool same0 = (i == ci0) && (j == cj0);  // still inside the start cell: never tested
-        const bool inb = slam_in_bounds(rows, cols, i, j);
-        if (!inb && !same0) return;  // slam/raycast.cpp:176
-        unsigned e = 0;
-        if (inb)
+        e = Ep[org + i * pitch + j];
+        if (reads) ++*reads;
+    }
+    if (e == 0 && left > 0)
+    {
+        // start cell occupied or outside the grid: samples still inside it are skipped by the
+        // reference's same-cell test; walk until the ray leaves it
+        const int ci0 = i, cj0 = j;
+        do
         {
-            e = E[(size_t)i * (size_t)cols + (size_t)j];
+            x += dx;
+            y += dy;
+            --left;
+            slam_cell_of(rows, x, y, &i, &j);
+        } while (i == ci0 && j == cj0 && left > 0);
+        if (i != ci0 || j != cj0)
+        {
+            if (!slam_in_bounds(rows, cols, i, j)) return;  // slam/raycast.cpp:176
+            e = Ep[org + i * pitch + j];
             if (reads) ++*reads;
+            if (e == 0)
+            {  // slam/raycast.cpp:183-189
+                res->hx = x;
+                res->hy = y;
+                res->hcell = i * cols + j;
+                return;
+            }
         }
-        if (e == 0 && !same0)
-        {  // slam/raycast.cpp:183-189
-            res->hx = X.v;
-            res->hy = Y.v;
-            res->hcell = i * cols + j;
-            return;
+    }
+    if (left > 0)
+    {
+        // (x, y) is an in-bounds sample with clearance e >= 1
+        slam_axis X = {x, 0.0, 0}, Y = {y, 0.0, 0};
+        slam_axis_setup(&X, dx);
+        slam_axis_setup(&Y, dy);
+        const float adx = (float)dm_fabs(dx), ady = (float)dm_fabs(dy);
+        // samples to advance = 1 + floor((e-1) * 0.9999 / max(|dx|,|dy|)), in 16.16 fixed point
+        const unsigned sc = (unsigned)(0.9999f * 65536.0f * slam_rcpf(adx > ady ? adx : ady));
+        const unsigned bias = 65536u - sc;
+        int rem = X.rem < Y.rem ? X.rem : Y.rem;  // samples the fma path may still take
+        if (rem > left) rem = left;
+        int rem0 = rem;
+        for (;;)
+        {
+            // advance m samples (any m' <= m would be legal too): one fma per axis ...
+            const int m = (int)((e * sc + bias) >> 16);
+            int t = m < rem ? m : rem;
+            rem -= t;
+            double tf = (double)t;
+            X.v = dm_fma(tf, X.inc, X.v);  // exact, see slam_axis
+            Y.v = dm_fma(tf, Y.inc, Y.v);
+            bool last = false;
+            if (t < m)
+            {
+                // ... unless a binade edge, a tie stretch, |coordinate| < 4 or the end of the
+                // distance-safe range is in the way: one real add per axis, then jump on
+                X.rem -= rem0;
+                Y.rem -= rem0;
+                left -= rem0;
+                if (left > 0)
+                {
+                    slam_axis_real_add(&X, dx);
+                    slam_axis_real_add(&Y, dy);
+                    left -= 1;
+                    rem = X.rem < Y.rem ? X.rem : Y.rem;
+                    if (rem > left) rem = left;
+                    rem0 = rem;
+                    t = m - t - 1;
+                    t = t < rem ? t : rem;
+                    rem -= t;
+                    tf = (double)t;
+                    X.v = dm_fma(tf, X.inc, X.v);
+                    Y.v = dm_fma(tf, Y.inc, Y.v);
+                }
+                else
+                {
+                    rem0 = 0;
+                    last = true;  // this sample is k_safe: test it, then continue with the literal loop
+                }
+            }
+            slam_cell_of(rows, X.v, Y.v, &i, &j);
+#ifdef SLAM_RAY_DEBUG
+            if (i < -2 || i > rows + 1 || j < -2 || j > cols + 1) __builtin_trap();  // frame guarantee violated
+#endif
+            e = Ep[org + i * pitch + j];
+            if (reads) ++*reads;
+            if (e == 0)
+            {
+                if (slam_in_bounds(rows, cols, i, j))
+                {  // slam/raycast.cpp:183-189
+                    res->hx = X.v;
+                    res->hy = Y.v;
+                    res->hcell = i * cols + j;
+                }
+                return;  // otherwise slam/raycast.cpp:176
+            }
+            if (last) break;
         }
-        if (k >= k_safe) break;
-        int m = 1;
-        if (e > 1) m += (int)((float)(e - 1) * scale);
-        if (m > k_safe - k) m = k_safe - k;
-        slam_advance(&X, &Y, dx, dy, m);
-        k += m;
+        x = X.v;
+        y = Y.v;
     }
     // tail: the literal loop from sample k_safe on (dedupe against the previous sample's cell,
     // bounds, hit, distance limit).
-    double x = X.v, y = Y.v;
     int pi = i, pj = j;
     for (int it = 0; it < 16; ++it)
     {
@@ -236,7 +354,7 @@ DM_HD void ray_fast_L(const uint8_t* E, int rows, int cols, double sx, double sy
         if (i == pi && j == pj) continue;
         if (!slam_in_bounds(rows, cols, i, j)) return;
         if (reads) ++*reads;
-        if (E[(size_t)i * (size_t)cols + (size_t)j] == 0)
+        if (Ep[org + i * pitch + j] == 0)
         {
             res->hx = x;
             res->hy = y;
@@ -253,8 +371,9 @@ DM_HD void ray_fast_L(const uint8_t* E, int rows, int cols, double sx, double sy
 // ------------------------------------------------------------------------------------------------
 // Beam likelihood, slam/raycast.cpp:233-241 + slam/util.cpp:9-19, returning log(w) for the
 // accumulation of slam/mcl.cpp:73.  norm = 1/(stddev*sqrt(2 pi)), z = sqrt(z2), zmax = sqrt(zmax2).
+// log_eps = dm_log(0.0 + 0.1): the value of every beam whose error exceeds 4 sigma (pdf clamp).
 DM_HD double slam_beam_logw(const slam_ray_result* r, double sx, double sy, double z, double zmax, double stddev,
-                            double norm)
+                            double norm, double log_eps)
 {
     double xarg;
     if (r->hx == -1.0)
@@ -264,11 +383,8 @@ DM_HD double slam_beam_logw(const slam_ray_result* r, double sx, double sy, doub
         const double ex = r->hx - sx, ey = r->hy - sy;
         xarg = dm_sqrt(ex * ex + ey * ey) - z;
     }
-    double p = 0.0;
-    if (!(dm_fabs(xarg) > 4.0 * stddev))
-    {
-        const double q = xarg / stddev;
-        p = norm * dm_exp(-0.5 * (q * q));
-    }
+    if (dm_fabs(xarg) > 4.0 * stddev) return log_eps;
+    const double q = xarg / stddev;
+    const double p = norm * dm_exp(-0.5 * (q * q));
     return dm_log(p + 0.1);
 }

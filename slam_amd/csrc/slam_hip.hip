@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <rocprim/rocprim.hpp>
@@ -80,8 +81,9 @@ struct slam_mcl
     bool have_map = false;
     // scan
     int Bcap = 0;
+    double* scan_dev = nullptr;  // [angle | dist^2 | sqrt(dist^2)], Bcap doubles each (packed at B)
     double *angles = nullptr, *z2 = nullptr, *z = nullptr;
-    std::vector<double> scan_cache;
+    std::vector<double> scan_cache, scan_prev;
     int last_B = 0;
     // noise
     double *inj_normals = nullptr, *inj_uniforms = nullptr;
@@ -101,6 +103,8 @@ struct slam_mcl
     size_t hit_cap = 0;
     unsigned long long* stats = nullptr;
     double* partials = nullptr;
+    double* lw = nullptr;  // scratch of the particle-lane weight kernels
+    size_t lw_cap = 0;     // doubles
     bool profile = false;
     std::vector<TimedSpan> spans;
     double acc_ms[G_COUNT] = {0, 0, 0, 0, 0};
@@ -184,12 +188,12 @@ int upload_scan(slam_mcl* h, const double* angles, const double* dists, int B)
         if (!std::isfinite(angles[b]) || !std::isfinite(dists[b])) return fail(SLAM_ERR_ARG, "scan: non-finite entry");
     if (B > h->Bcap)
     {
-        hipFree(h->angles);
-        hipFree(h->z2);
-        hipFree(h->z);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        hipFree(h->scan_dev);
+        h->scan_dev = nullptr;
         h->Bcap = 0;
-        int rc;
-        if ((rc = dev_alloc(&h->angles, B)) || (rc = dev_alloc(&h->z2, B)) || (rc = dev_alloc(&h->z, B))) return rc;
+        int rc = dev_alloc(&h->scan_dev, 3 * (size_t)B);
+        if (rc) return rc;
         h->Bcap = B;
         h->scan_cache.clear();
     }
@@ -202,12 +206,15 @@ int upload_scan(slam_mcl* h, const double* angles, const double* dists, int B)
         pack[B + b] = d2;
         pack[2 * (size_t)B + b] = std::sqrt(d2);
     }
+    h->angles = h->scan_dev;
+    h->z2 = h->scan_dev + B;
+    h->z = h->scan_dev + 2 * (size_t)B;
     if (h->last_B == B && h->scan_cache == pack) return SLAM_OK;  // same scan re-applied (benchmark/mcl.cpp:58-64)
-    HIPCHK(hipMemcpyAsync(h->angles, pack.data(), sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->z2, pack.data() + B, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->z, pack.data() + 2 * (size_t)B, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // stream-ordered copy from pageable memory: the runtime stages the bytes before returning, so
+    // `pack` may go out of scope and kernels already queued on the stream still see the old scan
+    HIPCHK(hipMemcpyAsync(h->scan_dev, pack.data(), sizeof(double) * 3 * (size_t)B, hipMemcpyHostToDevice, h->stream));
     h->scan_cache.swap(pack);
+    h->scan_prev.swap(pack);  // keep the previous host copy alive for one more generation
     h->last_B = B;
     return SLAM_OK;
 }
@@ -249,6 +256,11 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.zmax = std::sqrt(a.zmax2);        // slam/raycast.cpp:236
     a.stddev = stddev;
     a.norm = 1.0 / (stddev * std::sqrt(2 * M_PI));  // slam/util.cpp:11
+    a.log_eps = dm_log(0.0 + 0.1);                   // pdf clamped to 0 (slam/util.cpp:16) + EPSILON, slam/mcl.cpp:73
+    a.lw = nullptr;
+    a.p_first = 0;
+    a.npblocks = 0;
+    a.nseg = a.seg_beams = 0;
     // slam/mcl.cpp:80-86 with the int-returning squared distance of slam/util.h:138-146
     {
         const double ddx = 0 - off[0], ddy = 0 - off[1];
@@ -273,7 +285,50 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         a.grid = h->maps;
         hipLaunchKernelGGL(slamk::k_weights_S, dim3((unsigned)cdiv(h->n, 64)), dim3(64), 0, h->stream, a);
     }
-    else if (h->prm.raycaster == SLAM_RAYCAST_FAST)
+    else if (h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES ||
+             (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096))
+    {
+        // lane = particle; (64-particle block, beam segment) work items; see k_rays_pl
+        a.grid = h->clr;
+        const size_t cap_max = (size_t)64 << 20;  // 512 MiB of scratch at most
+        const int64_t pblocks_all = cdiv(h->n, 64);
+        int64_t pb_per_launch = (int64_t)(cap_max / ((size_t)B * 64));
+        if (pb_per_launch < 1) pb_per_launch = 1;
+        if (pb_per_launch > pblocks_all) pb_per_launch = pblocks_all;
+        const size_t need = (size_t)pb_per_launch * B * 64;
+        if (need > h->lw_cap)
+        {
+            hipFree(h->lw);
+            h->lw_cap = 0;
+            int rc = dev_alloc(&h->lw, need);
+            if (rc) return rc;
+            h->lw_cap = need;
+        }
+        a.lw = h->lw;
+        for (int64_t pb0 = 0; pb0 < pblocks_all; pb0 += pb_per_launch)
+        {
+            a.p_first = pb0 * 64;
+            a.npblocks = std::min(pb_per_launch, pblocks_all - pb0);
+            // enough work items to keep 8 waves on each of the 1024 SIMDs through the tail
+            int64_t want = cdiv(4 * 8192, a.npblocks);
+            if (want < 1) want = 1;
+            if (want > B) want = B;
+            a.seg_beams = (int)cdiv(B, want);
+            a.nseg = (int)cdiv(B, a.seg_beams);
+            const dim3 grid((unsigned)cdiv(a.npblocks * a.nseg, 4));
+            static const int pl_waves = getenv("SLAM_PL_WAVES") ? atoi(getenv("SLAM_PL_WAVES")) : 6;
+            if (pl_waves >= 8)
+                hipLaunchKernelGGL(slamk::k_rays_pl<8>, grid, dim3(256), 0, h->stream, a);
+            else if (pl_waves >= 6)
+                hipLaunchKernelGGL(slamk::k_rays_pl<6>, grid, dim3(256), 0, h->stream, a);
+            else if (pl_waves >= 5)
+                hipLaunchKernelGGL(slamk::k_rays_pl<5>, grid, dim3(256), 0, h->stream, a);
+            else
+                hipLaunchKernelGGL(slamk::k_rays_pl<4>, grid, dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL(slamk::k_sum_lw, dim3((unsigned)cdiv(a.npblocks * 64, 256)), dim3(256), 0, h->stream, a);
+        }
+    }
+    else if (h->prm.raycaster == SLAM_RAYCAST_FAST || h->prm.raycaster == SLAM_RAYCAST_FAST_BEAM_LANES)
     {
         a.grid = h->clr;
         hipLaunchKernelGGL(slamk::k_weights_L<0>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
@@ -403,9 +458,9 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
         hipEventDestroy(s.b);
     }
     void* ptrs[] = {h->state, h->state2,
-                    h->grid,  h->clr,    h->maps, h->maps2,    h->luts,         h->angles, h->z2,   h->z,
+                    h->grid,  h->clr,    h->maps, h->maps2,    h->luts,         h->scan_dev,
                     h->inj_normals, h->inj_uniforms, h->idx, h->perm, h->slots, h->src,   h->keys, h->keys2,
-                    h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials};
+                    h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (size_t l = 0; l < h->lvl_s.size(); ++l)
@@ -555,15 +610,16 @@ SLAM_API int slam_mcl_set_map_u8(slam_mcl* h, const uint8_t* map, int32_t rows, 
     if (h->prm.mode != SLAM_MODE_LOCALIZATION) return fail(SLAM_ERR_STATE, "set_map_u8 is for localization mode");
     if (!map || rows != h->rows || cols != h->cols) return fail(SLAM_ERR_ARG, "map null or size differs from create()");
     const size_t bytes = (size_t)rows * cols;
+    const size_t pbytes = (size_t)(rows + 4) * (size_t)(cols + 4);  // clearance grid with its frame
     if (!h->grid)
     {
-        if ((rc = dev_alloc(&h->grid, bytes)) || (rc = dev_alloc(&h->clr, bytes))) return rc;
+        if ((rc = dev_alloc(&h->grid, bytes)) || (rc = dev_alloc(&h->clr, pbytes))) return rc;
     }
-    std::vector<uint8_t> E(bytes);
-    slam_build_clearance(map, rows, cols, E.data());
+    std::vector<uint8_t> E(pbytes);
+    slam_build_clearance_padded(map, rows, cols, E.data());
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->grid, map, bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->clr, E.data(), bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->clr, E.data(), pbytes, hipMemcpyHostToDevice));
     h->have_map = true;
     return SLAM_OK;
 }

@@ -91,7 +91,10 @@ def test_predict_philox_matches_host_stream_and_shards(sa):
 
 
 # ---- K2a raycast + likelihood, localization mode -------------------------------------------------
-@pytest.mark.parametrize("raycaster", ["fast", "walk"])
+RAYCASTERS = {"fast": 0, "walk": 1, "beam_lanes": 2, "particle_lanes": 3}
+
+
+@pytest.mark.parametrize("raycaster", ["beam_lanes", "particle_lanes", "walk"])
 @pytest.mark.parametrize("mapname,N,B,zmax,stddev", [("floor_plan", 600, 360, 500.0, 5.0), ("map", 300, 90, 500.0, 5.0),
                                                      ("maze", 200, 65, 150.5, 2.0), ("floor_plan", 128, 1, 40.0, 5.0)])
 def test_weights_localization(sa, raycaster, mapname, N, B, zmax, stddev):
@@ -104,7 +107,7 @@ def test_weights_localization(sa, raycaster, mapname, N, B, zmax, stddev):
     x, y, th = cloud(rng, N, true[0], true[1])
     x[:8] = rng.uniform(-60, cols + 60, 8)   # some particles outside / at the border
     y[:8] = rng.uniform(-60, rows + 60, 8)
-    f = sa.Filter(N, rows, cols, raycaster=sa.capi.RAYCAST_FAST if raycaster == "fast" else sa.capi.RAYCAST_WALK)
+    f = sa.Filter(N, rows, cols, raycaster=RAYCASTERS[raycaster])
     f.set_map(g)
     f.set_poses(x, y, th)
     f.record_hits(True)
@@ -132,7 +135,7 @@ def test_weights_degenerate_underflow_and_tiny_ranges(sa):
     rows, cols = g.shape
     N = 64
     x, y, th = cloud(rng, N, 500, 300)
-    f = sa.Filter(N, rows, cols)
+    f = sa.Filter(N, rows, cols, raycaster=sa.capi.RAYCAST_FAST_PARTICLE_LANES)
     f.set_map(g)
     f.set_poses(x, y, th)
     # sigma = 5 and B = 720 -> exp underflows to exactly 0 for every particle (SURVEY.md §7 hard part 4)

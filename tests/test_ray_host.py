@@ -1,0 +1,132 @@
+"""CPU checks of the device ray functions (slam_amd/csrc/ray.h compiled for the host by
+tests/host_harness): the exact-jump position update and the clearance-skipping hit search must give
+bit-identical results to plain repeated addition / the literal cell-by-cell walk."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P = ctypes.c_void_p
+
+
+@pytest.fixture(scope="module")
+def hh():
+    d = os.path.join(HERE, "host_harness")
+    subprocess.run(["make", "-C", d, "-s"], check=True)
+    lib = ctypes.CDLL(os.path.join(d, "libray_harness.so"))
+    lib.hh_rays_compare.restype = ctypes.c_long
+    lib.hh_advance_check.restype = ctypes.c_long
+    return lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(P)
+
+
+def advance_bad(hh, x0, y0, dx, dy, total, jumps):
+    j = np.ascontiguousarray(jumps, dtype=np.int32)
+    js = ctypes.c_long(0)
+    bad = hh.hh_advance_check(ctypes.c_double(x0), ctypes.c_double(y0), ctypes.c_double(dx), ctypes.c_double(dy),
+                              total, ptr(j), len(j), ctypes.byref(js))
+    return bad, js.value
+
+
+def test_exact_jumps_equal_repeated_addition(hh):
+    rng = np.random.default_rng(1)
+    jumped = 0
+    for t in range(6000):
+        th = rng.uniform(-np.pi, np.pi)
+        scale = 10.0 ** rng.uniform(-1, 4.3)
+        x0, y0 = rng.uniform(-1, 1) * scale, rng.uniform(-1, 1) * scale
+        if t % 3 == 0:  # small binades: ties (dx an odd multiple of ulp/2) are frequent there
+            x0, y0 = rng.uniform(0.9, 4.1), rng.uniform(0.4, 2.2)
+        dx, dy = np.cos(th), np.sin(th)
+        if t % 5 == 0:  # few significant bits -> exact ties
+            dx = np.round(dx * 2.0 ** rng.integers(3, 54)) / 2.0 ** 53 * 2.0 ** rng.integers(0, 3)
+        bad, js = advance_bad(hh, x0, y0, dx, dy, 600, rng.integers(1, 40, size=16))
+        assert bad == 0, (x0, y0, dx, dy)
+        jumped += js
+    for t in range(2000):  # forced ties on both axes
+        dx = (2 * int(rng.integers(2 ** 50, 2 ** 52)) + 1) * 2.0 ** -53
+        dy = -(2 * int(rng.integers(2 ** 50, 2 ** 52)) + 1) * 2.0 ** -53
+        bad, _ = advance_bad(hh, rng.uniform(1, 2), rng.uniform(2, 4), dx, dy, 300, rng.integers(1, 20, size=8))
+        assert bad == 0
+    for dx, dy in [(0.0, 1.0), (1.0, 0.0), (6.123233995736766e-17, 1.0), (-1.0, 1e-300), (2.0 ** -60, -1.0)]:
+        bad, _ = advance_bad(hh, 500.25, 0.75, dx, dy, 800, [1, 7, 64, 255, 3])
+        assert bad == 0
+    assert jumped > 0.5 * 6000 * 600, "the fma fast path should carry most samples"
+
+
+def compare(hh, grid, sx, sy, th, zmax):
+    rows, cols = grid.shape
+    E = np.empty_like(grid)
+    hh.hh_build_clearance(ptr(grid), rows, cols, ptr(E))
+    n = sx.size
+    fb, rf, rw = ctypes.c_long(), ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    hits = np.empty((n, 2))
+    bad = hh.hh_rays_compare(ptr(grid), ptr(E), rows, cols, ctypes.c_long(n), ptr(sx), ptr(sy), ptr(th),
+                             ctypes.c_double(zmax), ctypes.byref(fb), ctypes.byref(rf), ctypes.byref(rw), ptr(hits))
+    return bad, fb.value, rf.value / n, rw.value / n, hits, E
+
+
+@pytest.mark.parametrize("name", ["floor_plan", "map", "maze"])
+def test_fast_hit_search_equals_literal_walk(hh, name):
+    rng = np.random.default_rng(2)
+    g = (orc.load_map(name) * 255).astype(np.uint8)
+    rows, cols = g.shape
+    for n, zmax, spread in [(60000, 500.0, 0), (20000, 500.0, 60), (20000, 37.25, 0), (10000, 0.7, 0), (10000, 1.0, 5),
+                            (5000, 4000.0, 0)]:
+        sx, sy = rng.uniform(-spread, cols + spread, n), rng.uniform(-spread, rows + spread, n)
+        th = rng.uniform(-7, 7, n)
+        bad, first, rfast, rwalk, hits, _ = compare(hh, g, sx, sy, th, zmax)
+        assert bad == 0, f"{name} zmax={zmax}: {bad} rays differ, first {first}: {sx[first]!r} {sy[first]!r} {th[first]!r}"
+        if zmax >= 500:
+            assert rfast < 0.1 * rwalk  # the point of the clearance grid
+    # grid-aligned starts and axis/diagonal directions (cell edges, exact ties)
+    n = 40000
+    sx, sy = rng.integers(0, cols, n).astype(float), rng.integers(0, rows, n).astype(float)
+    th = rng.integers(0, 8, n) * (np.pi / 4)
+    assert compare(hh, g, sx, sy, th, 500.0)[0] == 0
+    # far outside the grid, including the coordinate range where only the literal loop is used
+    sx = np.array([-1e7, 3e6, 2e9, -5e9, 1e15, 100.0, cols + 0.5])
+    sy = np.array([10.0, -4e6, 2e9, 7.0, 3.0, -2e6, rows - 0.5])
+    th = np.array([0.0, 1.0, 2.0, 3.0, -1.0, 1.5707963267948966, 3.0])
+    assert compare(hh, g, sx, sy, th, 500.0)[0] == 0
+
+
+def test_fast_hit_search_matches_the_oracle_walk(hh):
+    """The harness' literal walk is the same source as the kernels'; tie it to the oracle as well."""
+    rng = np.random.default_rng(3)
+    g = (orc.load_map("floor_plan") * 255).astype(np.uint8)
+    rows, cols = g.shape
+    n = 3000
+    sx, sy, th = rng.uniform(0, cols, n), rng.uniform(0, rows, n), rng.uniform(-4, 4, n)
+    bad, _, _, _, hits, _ = compare(hh, g, sx, sy, th, 500.0)
+    assert bad == 0
+    for r in range(n):
+        h, cell, _ = orc.raycast_mapping(g, sx[r], sy[r], th[r], 250000.0, 250000.0, write=False, math=orc.DET)
+        assert h[0] == hits[r, 0] and h[1] == hits[r, 1]
+
+
+def test_clearance_grid_brute_force(hh):
+    rng = np.random.default_rng(4)
+    for shape, dens in [((60, 70), 0.03), ((33, 17), 0.2), ((5, 300), 0.0), ((1, 1), 0.0)]:
+        m = ((rng.uniform(size=shape) >= dens) * 255).astype(np.uint8)
+        E = np.empty_like(m)
+        hh.hh_build_clearance(ptr(m), shape[0], shape[1], ptr(E))
+        occ = np.argwhere(m < 128)
+        for i in range(shape[0]):
+            for j in range(shape[1]):
+                if m[i, j] < 128:
+                    exp = 0
+                else:
+                    d = min(i + 1, shape[0] - i, j + 1, shape[1] - j)
+                    if len(occ):
+                        d = min(d, int(np.max(np.abs(occ - [i, j]), axis=1).min()))
+                    exp = min(d, 255)
+                assert E[i, j] == exp
