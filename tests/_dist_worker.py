@@ -1,0 +1,82 @@
+"""Worker of tests/test_dist_cpu.py: runs slam_amd.dist.ShardedFilter over `gloo` with a CPU shard
+backend built from the oracle (TEST ONLY — the product backend is HipShard).  Each rank writes its
+final shard state to <out>/rank<r>.npz."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import _oracle as orc  # noqa: E402
+from slam_amd.dist import ShardedFilter  # noqa: E402
+
+ODOM, ALPHAS, OFFSET = [2.5, 0.02, 0.02], [5e-4, 5e-4, 1e-2, 1e-2], [0.0, 30.0, 0.0]
+
+
+class OracleShard:
+    """Same interface as slam_amd.dist.HipShard, computed by the CPU oracle (detmath mode)."""
+
+    def __init__(self, n_local, rank, world, seed, grid, x, y, th):
+        self.n, self.rank, self.world, self.seed, self.grid = n_local, rank, world, seed, grid
+        self.first = rank * n_local
+        self.x, self.y, self.th = x.copy(), y.copy(), th.copy()
+        self.w = np.full(n_local, 1.0 / (world * n_local))
+        self.pstep = self.rstep = 0
+        self.last_idx = None
+
+    def predict(self, odom, alphas):
+        z = orc.philox_normals(self.seed, self.pstep, self.first, self.n)
+        self.x, self.y, self.th = orc.predict(self.x, self.y, self.th, odom, alphas, z, math=orc.DET)
+        self.pstep += 1
+
+    def update_weights(self, angles, dists, stddev, max_dist, offset):
+        self.w, _ = orc.update_weights(self.x, self.y, self.th, self.grid, angles, dists, stddev, max_dist, offset,
+                                       math=orc.DET)
+
+    def packed_state(self):
+        return torch.from_numpy(np.concatenate([self.x, self.y, self.th, self.w]))
+
+    def new_gather_buffer(self, world):
+        return torch.empty(world * 4 * self.n, dtype=torch.float64)
+
+    def shard_resample(self, gathered, world):
+        g = gathered.numpy().reshape(world, 4, self.n)
+        allx, ally, allth, allw = (g[:, q, :].reshape(-1) for q in range(4))
+        N = world * self.n
+        u = np.zeros(N)
+        u[self.first:self.first + self.n] = orc.philox_uniforms(self.seed, self.rstep, self.first, self.n)
+        idx, _, _ = orc.resample(allw, u, orc.ORDER_BLOCKED)
+        idx = idx[self.first:self.first + self.n]
+        self.x, self.y, self.th, self.w = allx[idx].copy(), ally[idx].copy(), allth[idx].copy(), allw[idx].copy()
+        self.last_idx = idx
+        self.rstep += 1
+
+
+def main():
+    out, n_total, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_loc = n_total // world
+    free = orc.load_map("floor_plan")
+    grid = (free * 255).astype(np.uint8)
+    rng = np.random.default_rng(5)
+    x, y, th = 520 + 20 * rng.standard_normal(n_total), 280 + 20 * rng.standard_normal(n_total), 0.4 + 0.2 * rng.standard_normal(n_total)
+    sl = slice(rank * n_loc, (rank + 1) * n_loc)
+    shard = OracleShard(n_loc, rank, world, 0xD157, grid, x[sl], y[sl], th[sl])
+    sf = ShardedFilter(shard, world=world)
+    ang, dscan = orc.make_scan(free, [520.0, 280.0, 0.4], OFFSET, 45)
+    for _ in range(steps):
+        sf.predict(ODOM, ALPHAS)
+        sf.update(ang, dscan, 5.0, 500.0, OFFSET)
+    np.savez(os.path.join(out, f"rank{rank}.npz"), x=shard.x, y=shard.y, th=shard.th, w=shard.w, idx=shard.last_idx)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
