@@ -245,6 +245,181 @@ __global__ void __launch_bounds__(64) k_weights_S(WeightArgs a)
     }
 }
 
+// K2b, wave form (small and medium N).  One wavefront per particle; beams strictly in order
+// (slam/mcl.cpp:69-74: later beams see earlier beams' writes); inside one ray the 64 lanes take 64
+// consecutive samples.  Sample positions are exact (slam_advance from a wave-uniform base), the
+// loop-carried decisions of slam/raycast.cpp:163-220 (first hit, first cell at or beyond z, stop at
+// zmax / leaving the grid / drew && foundHit) are resolved with ballots, and only the cells the
+// reference would have processed are written.  Cells of one ray are distinct (coordinates move
+// monotonically), so reading every lane's cell before any write sees exactly what the sequential
+// loop sees.
+struct WaveRay
+{
+    double hx, hy;
+    int hcell;
+    unsigned n_read, n_written, n_steps;
+};
+
+__device__ __forceinline__ uint64_t lanes_upto(int l) { return l >= 63 ? ~0ull : ((1ull << (l + 1)) - 1ull); }
+
+__device__ void ray_walk_wave(uint8_t* map, int rows, int cols, double sx, double sy, double dx, double dy, double z2,
+                              double zmax2, const uint8_t* lut_free, const uint8_t* lut_occ, int max_iter, int lane,
+                              WaveRay* out)
+{
+    slam_axis Xb = {sx, 0.0, 0}, Yb = {sy, 0.0, 0};
+    slam_axis_setup(&Xb, dx);
+    slam_axis_setup(&Yb, dy);
+    int pi, pj;
+    slam_cell_of(rows, sx, sy, &pi, &pj);
+    bool drew = false, found = false;
+    out->hx = -1.0;
+    out->hy = -1.0;
+    out->hcell = -1;
+    out->n_read = out->n_written = 0;
+    out->n_steps = (unsigned)max_iter;
+    const bool draw_occ = (z2 != zmax2);  // slam/raycast.cpp:205
+    for (int k0 = 0; k0 < max_iter; k0 += 64)
+    {
+        slam_axis X = Xb, Y = Yb;
+        slam_advance(&X, &Y, dx, dy, lane + 1);  // sample k0 + lane + 1, exact
+        int i, j;
+        slam_cell_of(rows, X.v, Y.v, &i, &j);
+        int qi = __shfl_up(i, 1, 64), qj = __shfl_up(j, 1, 64);
+        if (lane == 0)
+        {
+            qi = pi;
+            qj = pj;
+        }
+        const int last_exist = (max_iter - k0 - 1) < 63 ? (max_iter - k0 - 1) : 63;
+        const bool isnew = (lane <= last_exist) && !(i == qi && j == qj);  // slam/raycast.cpp:171-174
+        const bool inb = slam_in_bounds(rows, cols, i, j);
+        const size_t off = (size_t)i * (size_t)cols + (size_t)j;
+        uint8_t c = 255;
+        if (isnew && inb) c = map[off];
+        const double ex = X.v - sx, ey = Y.v - sy;
+        const double d2 = ex * ex + ey * ey;
+        const bool far = !(d2 < z2);
+        const uint64_t m_new = __ballot(isnew);
+        const uint64_t m_oob = __ballot(isnew && !inb);
+        const uint64_t m_occ = __ballot(isnew && inb && c < 128);
+        const uint64_t m_far = __ballot(isnew && far);
+        const uint64_t m_vfar = __ballot(isnew && d2 >= zmax2);
+        const int f_oob = m_oob ? __builtin_ctzll(m_oob) : 64;                  // break before processing (:176)
+        const int f_hit = found ? -1 : (m_occ ? __builtin_ctzll(m_occ) : 64);   // :183-189
+        const int f_far = drew ? -1 : (m_far ? __builtin_ctzll(m_far) : 64);    // :203-214
+        const int f_vfar = m_vfar ? __builtin_ctzll(m_vfar) : 64;               // break after processing (:216)
+        const int both = f_hit > f_far ? f_hit : f_far;                         // loop condition fails after this lane (:163)
+        const int stop_incl = both < f_vfar ? both : f_vfar;
+        const int term = stop_incl < f_oob ? stop_incl : f_oob;                 // lane whose step ends the ray
+        int lim = stop_incl < (f_oob - 1) ? stop_incl : (f_oob - 1);            // last processed lane
+        if (lim > last_exist) lim = last_exist;
+        if (!found && f_hit <= lim)
+        {
+            out->hx = __shfl(X.v, f_hit, 64);
+            out->hy = __shfl(Y.v, f_hit, 64);
+            out->hcell = __shfl(i, f_hit, 64) * cols + __shfl(j, f_hit, 64);
+            found = true;
+        }
+        const bool proc = isnew && lane <= lim;
+        const bool wr = proc && (!far || (lane == f_far && draw_occ));
+        if (wr) map[off] = far ? lut_occ[c] : lut_free[c];
+        if (!drew && f_far <= lim) drew = true;
+        if (lim >= 0)
+        {
+            out->n_read += (unsigned)__builtin_popcountll(m_new & lanes_upto(lim));
+            out->n_written += (unsigned)__builtin_popcountll(__ballot(wr));
+        }
+        if (term <= last_exist)
+        {
+            out->n_steps = (unsigned)(k0 + term + 1);
+            return;
+        }
+        if (last_exist < 63) return;  // max_iter reached (the reference would spin here)
+        Xb.v = __shfl(X.v, 63, 64);
+        Xb.inc = __shfl(X.inc, 63, 64);
+        Xb.rem = __shfl(X.rem, 63, 64);
+        Yb.v = __shfl(Y.v, 63, 64);
+        Yb.inc = __shfl(Y.inc, 63, 64);
+        Yb.rem = __shfl(Y.rem, 63, 64);
+        pi = __shfl(i, 63, 64);
+        pj = __shfl(j, 63, 64);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_weights_S_wave(WeightArgs a)
+{
+    __shared__ uint8_t luts[512];
+    for (int t = threadIdx.x; t < 512; t += blockDim.x) luts[t] = a.luts[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= a.n) return;  // whole wavefront
+    uint8_t* map = a.grid + a.map_stride * (size_t)p;
+    const double px = a.x[p], py = a.y[p], pth = a.th[p];
+    double s0, c0;
+    dm_sincos(pth + a.stheta, &s0, &c0);
+    const double sx = px + c0 * a.sd;
+    const double sy = py + s0 * a.sd;
+    double acc = 0.0;
+    unsigned long long n_read = 0, n_written = 0, n_steps = 0;
+    for (int b0 = 0; b0 < a.B; b0 += 64)
+    {
+        // directions of up to 64 beams at once (lane = beam) ...
+        const int b = b0 + lane;
+        double mydx = 0.0, mydy = 0.0, myz2 = 0.0;
+        if (b < a.B)
+        {
+            dm_sincos(pth + a.angles[b] + a.srot, &mydy, &mydx);
+            myz2 = a.z2[b];
+        }
+        slam_ray_result mine = {-1.0, -1.0, -1};
+        const int cnt = (a.B - b0) < 64 ? (a.B - b0) : 64;
+        // ... then the rays one after the other, 64 samples of one ray per pass
+        for (int q = 0; q < cnt; ++q)
+        {
+            WaveRay wr;
+            ray_walk_wave(map, a.rows, a.cols, sx, sy, __shfl(mydx, q, 64), __shfl(mydy, q, 64), __shfl(myz2, q, 64),
+                          a.zmax2, luts, luts + 256, a.max_iter, lane, &wr);
+            if (lane == q)
+            {
+                mine.hx = wr.hx;
+                mine.hy = wr.hy;
+                mine.hcell = wr.hcell;
+            }
+            n_read += wr.n_read;
+            n_written += wr.n_written;
+            n_steps += wr.n_steps;
+            // the next ray of this wavefront must see these stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        // likelihoods of the batch (lane = beam), added in beam order
+        double lw = 0.0;
+        if (b < a.B)
+        {
+            lw = slam_beam_logw(&mine, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
+            if (a.hit_xy)
+            {
+                const size_t o = (size_t)p * a.B + b;
+                a.hit_xy[2 * o] = mine.hx;
+                a.hit_xy[2 * o + 1] = mine.hy;
+                a.hit_cell[o] = mine.hcell;
+            }
+        }
+        for (int l = 0; l < cnt; ++l) acc += readlane_f64(lw, l);
+    }
+    if (lane == 0)
+    {
+        a.w[p] = dm_exp(acc);
+        if (a.stats)
+        {
+            atomicAdd(&a.stats[0], n_read);
+            atomicAdd(&a.stats[1], n_written);
+            atomicAdd(&a.stats[2], n_steps);
+        }
+    }
+}
+
 // Particle state is stored packed, [x | y | theta | weight], n doubles each.  A "gathered" buffer
 // holds the packed states of all shards back to back ([shard][4][n_loc]), which is exactly what an
 // all-gather of the per-shard buffers produces.

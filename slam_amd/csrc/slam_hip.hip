@@ -283,7 +283,14 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     if (slam_mode)
     {
         a.grid = h->maps;
-        hipLaunchKernelGGL(slamk::k_weights_S, dim3((unsigned)cdiv(h->n, 64)), dim3(64), 0, h->stream, a);
+        // wave per particle (64 samples of a ray per pass) while that still fills the chip; one
+        // thread per particle beyond (SLAM_RAYCAST_* force a shape: 2 = wave, 3 = thread)
+        const bool wave = h->prm.raycaster == SLAM_RAYCAST_FAST_BEAM_LANES ||
+                          (h->prm.raycaster != SLAM_RAYCAST_FAST_PARTICLE_LANES && h->n < 262144);
+        if (wave)
+            hipLaunchKernelGGL(slamk::k_weights_S_wave, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL(slamk::k_weights_S, dim3((unsigned)cdiv(h->n, 64)), dim3(64), 0, h->stream, a);
     }
     else if (h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES ||
              (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096))

@@ -155,19 +155,23 @@ def test_weights_degenerate_underflow_and_tiny_ranges(sa):
 
 
 # ---- K2b SLAM mode: raycast + likelihood + occupancy update ---------------------------------------
-def test_weights_slam_mode_maps_bit_exact(sa):
+@pytest.mark.parametrize("shape", ["wave", "thread"])
+@pytest.mark.parametrize("B,zmax", [(90, 500.0), (130, 61.5)])
+def test_weights_slam_mode_maps_bit_exact(sa, shape, B, zmax):
     rng = np.random.default_rng(21)
-    N, B, rows, cols = 48, 90, 300, 400
+    N, rows, cols = 48, 300, 400
     free = orc.load_map("map")
-    ang, dist = orc.make_scan(free, [400.0, 400.0, np.pi / 90], OFFSET, B)
-    f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM)
+    ang, dist = orc.make_scan(free, [400.0, 400.0, np.pi / 90], OFFSET, B, max_dist=zmax)
+    f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM,
+                  raycaster=sa.capi.RAYCAST_FAST_BEAM_LANES if shape == "wave" else sa.capi.RAYCAST_FAST_PARTICLE_LANES)
     x, y, th = cloud(rng, N, cols / 2, rows / 2, sxy=6.0, sth=0.3, th0=np.pi / 2)
+    x[:3], y[:3] = [2.5, cols - 1.5, -20.0], [rows - 2.5, 1.5, 100.0]   # at the canvas border / outside
     f.set_poses(x, y, th)
     maps = np.full((N, rows, cols), 128, np.uint8)
     f.record_hits(True)
     for it in range(3):  # repeated scans: later passes see earlier writes (hits appear from pass 2 on)
-        f.update_weights(ang, dist, 5.0, 500.0, OFFSET)
-        ow, oxy, ocell, ost = orc.update_weights(x, y, th, maps, ang, dist, 5.0, 500.0, OFFSET, slam_mode=True,
+        f.update_weights(ang, dist, 5.0, zmax, OFFSET)
+        ow, oxy, ocell, ost = orc.update_weights(x, y, th, maps, ang, dist, 5.0, zmax, OFFSET, slam_mode=True,
                                                  want_hits=True, math=orc.DET)
         hxy, hcell = f.hits()
         assert np.array_equal(hcell, ocell)
