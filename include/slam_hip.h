@@ -169,6 +169,12 @@ int slam_fake_lidar_scan(int32_t device, const uint8_t* map01, int32_t rows, int
 int slam_raycast_u8(int32_t device, const uint8_t* map, int32_t rows, int32_t cols, const double* poses3, int64_t n,
                     double max_distance_squared, double step_size, double* hits_xy);
 
+/* Any of the read-only raycasts of slam/raycast.cpp:7-141, batched: kind 1 = unsigned char map
+ * (tests distance, bounds, then `< 128`; a double map thresholded at 0.5 by the caller follows the
+ * same order), kind 2 = int map given as uint8 0/1 (tests bounds, distance, then `== 0`). */
+int slam_raycast_batch(int32_t device, int32_t kind, const uint8_t* map, int32_t rows, int32_t cols, const double* poses3,
+                       int64_t n, double max_distance_squared, double step_size, double* hits_xy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,7 @@ SYMBOLS = {
     "slam_mcl_synchronize": (ctypes.c_int, [_P]),
     "slam_fake_lidar_scan": (ctypes.c_int, [_I32, _P, _I32, _I32, _P, _I32, _D, _D, _D, _I32, _P]),
     "slam_raycast_u8": (ctypes.c_int, [_I32, _P, _I32, _I32, _P, _I64, _D, _D, _P]),
+    "slam_raycast_batch": (ctypes.c_int, [_I32, _I32, _P, _I32, _I32, _P, _I64, _D, _D, _P]),
 }
 
 _lib = None

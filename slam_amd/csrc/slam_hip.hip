@@ -1038,3 +1038,19 @@ SLAM_API int slam_raycast_u8(int32_t device, const uint8_t* map, int32_t rows, i
     }
     return raycast_batch<1>(device, map, rows, cols, px, py, pth, max_distance_squared, step_size, hits_xy);
 }
+
+SLAM_API int slam_raycast_batch(int32_t device, int32_t kind, const uint8_t* map, int32_t rows, int32_t cols,
+                                const double* poses3, int64_t n, double max_distance_squared, double step_size,
+                                double* hits_xy)
+{
+    if (!poses3 || n <= 0 || (kind != 1 && kind != 2)) return fail(SLAM_ERR_ARG, "raycast_batch: bad argument");
+    std::vector<double> px(n), py(n), pth(n);
+    for (int64_t k = 0; k < n; ++k)
+    {
+        px[k] = poses3[3 * k];
+        py[k] = poses3[3 * k + 1];
+        pth[k] = poses3[3 * k + 2];
+    }
+    return kind == 1 ? raycast_batch<1>(device, map, rows, cols, px, py, pth, max_distance_squared, step_size, hits_xy)
+                     : raycast_batch<2>(device, map, rows, cols, px, py, pth, max_distance_squared, step_size, hits_xy);
+}

@@ -1,0 +1,196 @@
+// slam_host.cpp — C++ shim: the reference's public classes over the C ABI of libslam_hip.so.
+// Errors from the library are fatal here (the reference's interface returns void everywhere).
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/slam_hip.h"
+#include "../include/slam/fake_lidar.h"
+#include "../include/slam/mcl.h"
+#include "../include/slam/motion.h"
+#include "../include/slam/raycast.h"
+#include "../include/slam/util.h"
+
+namespace
+{
+void check(int rc, const char* what)
+{
+    if (rc != SLAM_OK) throw std::runtime_error(std::string(what) + ": " + slam_last_error());
+}
+}  // namespace
+
+namespace slam
+{
+MCL::MCL(int n_particles, const cv::Size& canvas_size) : m_canvas_size(canvas_size), m_n(n_particles)
+{
+    slam_mcl_params p{};
+    p.struct_size = sizeof(p);
+    p.mode = SLAM_MODE_SLAM;
+    p.n_particles = n_particles;
+    p.rows = canvas_size.height;
+    p.cols = canvas_size.width;
+    p.device = std::getenv("SLAM_DEVICE") ? std::atoi(std::getenv("SLAM_DEVICE")) : 0;
+    p.noise = SLAM_NOISE_PHILOX;
+    // the reference seeds from the clock (slam/util.cpp:30); SLAM_SEED makes a run repeatable
+    p.seed = std::getenv("SLAM_SEED") ? std::strtoull(std::getenv("SLAM_SEED"), nullptr, 0)
+                                      : static_cast<uint64_t>(std::chrono::system_clock::now().time_since_epoch().count());
+    p.sort = SLAM_SORT_FULL;
+    check(slam_mcl_create(&p, &m_handle), "slam_mcl_create");
+}
+
+MCL::~MCL() { slam_mcl_destroy(m_handle); }
+
+Pose MCL::starting_pose() const { return {m_canvas_size.width / 2.0, m_canvas_size.height / 2.0, M_PI / 2}; }
+
+void MCL::predict(const Odometry& odom, const std::array<double, 4>& alphas)
+{
+    const double o[3] = {odom.rotation_1, odom.translation, odom.rotation_2};
+    check(slam_mcl_predict(m_handle, o, alphas.data()), "slam_mcl_predict");
+    m_dirty = true;
+}
+
+void MCL::update(const std::vector<std::tuple<double, double>>& scan, double stddev, double max_dist,
+                 const Pose& scanner_offset, int /*n_threads*/)
+{
+    std::vector<double> ang(scan.size()), dist(scan.size());
+    for (size_t k = 0; k < scan.size(); ++k) std::tie(ang[k], dist[k]) = scan[k];
+    const double off[3] = {scanner_offset.x, scanner_offset.y, scanner_offset.theta};
+    check(slam_mcl_update(m_handle, ang.data(), dist.data(), static_cast<int32_t>(scan.size()), stddev, max_dist, off),
+          "slam_mcl_update");
+    m_dirty = true;
+}
+
+cv::Mat MCL::particle_map(int index) const
+{
+    cv::Mat m(m_canvas_size, CV_8UC1, cv::Scalar(0));
+    check(slam_mcl_get_map_u8(m_handle, index, &m.at<unsigned char>(0, 0)), "slam_mcl_get_map_u8");
+    return m;
+}
+
+const std::vector<Particle>& MCL::get_particles() const
+{
+    if (m_dirty)
+    {
+        std::vector<double> x(m_n), y(m_n), th(m_n), w(m_n);
+        check(slam_mcl_get_poses(m_handle, x.data(), y.data(), th.data(), 0, m_n), "slam_mcl_get_poses");
+        check(slam_mcl_get_weights(m_handle, w.data(), 0, m_n), "slam_mcl_get_weights");
+        m_particles.assign(m_n, Particle{});
+        for (int k = 0; k < m_n; ++k)
+        {
+            m_particles[k].pose = {x[k], y[k], th[k]};
+            m_particles[k].weight = w[k];
+        }
+        m_particles.front().map = particle_map(0);
+        m_dirty = false;
+    }
+    return m_particles;
+}
+
+Pose MCL::sensor_position(const Pose& frame_position, const Pose& scanner_offset)
+{
+    // slam/mcl.cpp:80-100; the squared distance passes through an int (slam/util.h:138-146)
+    const double ddx = 0 - scanner_offset.x, ddy = 0 - scanner_offset.y;
+    const double d = std::sqrt(static_cast<double>(static_cast<int>(ddx * ddx + ddy * ddy)));
+    const double theta = std::atan2(scanner_offset.y, scanner_offset.x);
+    Pose ret = frame_position;
+    ret.x += std::cos(frame_position.theta + theta) * d;
+    ret.y += std::sin(frame_position.theta + theta) * d;
+    ret.theta += scanner_offset.theta;
+    return ret;
+}
+
+// ---- caller-side helpers (single pose, host) -------------------------------------------------------
+double normalize_angle(double angle)
+{
+    angle = std::fmod(angle, 2 * M_PI);
+    if (angle > M_PI) angle -= 2 * M_PI;
+    return angle;
+}
+
+Pose sample_motion_model_odometry(const Odometry& odom, const Pose& pose, std::array<double, 4> alphas)
+{
+    // slam/motion.cpp:9-32 for ONE pose (the ground-truth robot of the callers), noise as in slam/util.cpp:27-34
+    auto sample = [](double stddev) {
+        static thread_local std::default_random_engine generator;
+        generator.seed(std::chrono::system_clock::now().time_since_epoch().count());
+        std::normal_distribution<double> distribution(0, stddev);
+        return distribution(generator);
+    };
+    const double r1 = odom.rotation_1 - sample(std::sqrt(alphas[0] * std::pow(odom.rotation_1, 2) + alphas[1] * std::pow(odom.translation, 2)));
+    const double t = odom.translation - sample(std::sqrt(alphas[2] * std::pow(odom.translation, 2) +
+                                                         alphas[3] * (std::pow(odom.rotation_1, 2) + std::pow(odom.rotation_2, 2))));
+    const double r2 = odom.rotation_2 - sample(std::sqrt(alphas[0] * std::pow(odom.rotation_2, 2) + alphas[1] * std::pow(odom.translation, 2)));
+    return {pose.x + t * std::cos(pose.theta + r1), pose.y + t * std::sin(pose.theta + r1), normalize_angle(pose.theta + r1 + r2)};
+}
+
+Pose average_pose(const std::vector<Particle>& particles)
+{
+    double ax = 0, ay = 0, tx = 0, ty = 0;
+    for (const Particle& p : particles)
+    {
+        ax += p.pose.x;
+        ay += p.pose.y;
+        tx += std::cos(p.pose.theta);
+        ty += std::sin(p.pose.theta);
+    }
+    return {ax / particles.size(), ay / particles.size(), std::atan2(ty, tx)};
+}
+
+// ---- scan synthesis and read-only raycasts on the GPU --------------------------------------------------
+std::vector<Pose> FakeLidar::scan(const cv::Mat& map, const Pose& pose) const
+{
+    std::vector<uint8_t> m01(static_cast<size_t>(map.rows) * map.cols);
+    for (int i = 0; i < map.rows; ++i)
+        for (int j = 0; j < map.cols; ++j) m01[static_cast<size_t>(i) * map.cols + j] = map.at<int>(i, j) ? 1 : 0;
+    const double p3[3] = {pose.x, pose.y, pose.theta};
+    std::vector<double> hits(2 * static_cast<size_t>(n_rays));
+    check(slam_fake_lidar_scan(0, m01.data(), map.rows, map.cols, p3, 1, start, stop, max_dist, n_rays, hits.data()),
+          "slam_fake_lidar_scan");
+    // slam/fake_lidar.cpp:23-30: every returned pose carries the ray's own angle
+    const double range = stop - start, step = range / n_rays;
+    std::vector<Pose> out(n_rays);
+    double theta = pose.theta;
+    theta -= range / 2;
+    for (int r = 0; r < n_rays; ++r)
+    {
+        out[r] = {hits[2 * r], hits[2 * r + 1], theta};
+        theta += step;
+    }
+    return out;
+}
+
+namespace
+{
+template <class T, class F>
+Pose raycast_one(const cv::Mat& map, const Pose& pose, double max2, double step, int kind, F to_u8)
+{
+    std::vector<uint8_t> m(static_cast<size_t>(map.rows) * map.cols);
+    for (int i = 0; i < map.rows; ++i)
+        for (int j = 0; j < map.cols; ++j) m[static_cast<size_t>(i) * map.cols + j] = to_u8(map.at<T>(i, j));
+    const double p3[3] = {pose.x, pose.y, pose.theta};
+    double hit[2];
+    check(slam_raycast_batch(0, kind, m.data(), map.rows, map.cols, p3, 1, max2, step, hit), "slam_raycast_batch");
+    return {hit[0], hit[1], pose.theta};
+}
+}  // namespace
+
+template <>
+Pose raycast<unsigned char>(const cv::Mat& map, const Pose& pose, double max2, double step)
+{
+    return raycast_one<unsigned char>(map, pose, max2, step, 1, [](unsigned char v) { return v; });
+}
+template <>
+Pose raycast<double>(const cv::Mat& map, const Pose& pose, double max2, double step)
+{
+    return raycast_one<double>(map, pose, max2, step, 1, [](double v) { return static_cast<uint8_t>(v < 0.5 ? 0 : 255); });
+}
+template <>
+Pose raycast<int>(const cv::Mat& map, const Pose& pose, double max2, double step)
+{
+    return raycast_one<int>(map, pose, max2, step, 2, [](int v) { return static_cast<uint8_t>(v ? 1 : 0); });
+}
+}  // namespace slam

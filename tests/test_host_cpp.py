@@ -1,0 +1,67 @@
+"""The C++ drop-in shim (slam_amd/host): slam::MCL / FakeLidar / motion with the reference's signatures,
+driven by the reference benchmark's call sequence (tests/host_cpp/mcl_like_benchmark.cpp mirrors
+benchmark/mcl.cpp:14-64)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EXE = os.path.join(HERE, "host_cpp", "mcl_like_benchmark")
+
+
+def test_shim_builds_against_the_c_abi_only():
+    subprocess.run(["make", "-C", os.path.join(HERE, "host_cpp"), "-s"], check=True)
+    assert os.path.exists(EXE)
+    src = open(os.path.join(HERE, "..", "slam_amd", "host", "src", "slam_host.cpp")).read()
+    assert "hip_runtime" not in src and "slam_hip.h" in src  # host C++ reaches HIP only through the C ABI
+
+
+@pytest.mark.gpu
+def test_cpp_shim_matches_python_path(tmp_path):
+    import slam_amd as sa
+    from slam_amd import capi
+
+    free = orc.load_map("floor_plan").astype(np.int32)
+    raw = tmp_path / "map.raw"
+    free.tofile(raw)
+    iters, seed = 4, 0x1234ABCD
+    env = dict(os.environ, SLAM_SEED=str(seed))
+    out = subprocess.run([EXE, str(raw), str(free.shape[0]), str(free.shape[1]), str(iters)], check=True, env=env,
+                         capture_output=True, text=True, timeout=300).stdout.splitlines()
+    parts = np.array([[int(t, 16) for t in ln.split()[1:]] for ln in out if ln.startswith("P ")], dtype=np.uint64)
+    avg = np.array([float(t) for t in next(ln for ln in out if ln.startswith("AVG")).split()[1:]])
+    # the same sequence through the Python mirror
+    off = sa.Pose(0, 30, 0)
+    sensor = sa.MCL.sensor_position(sa.Pose(400, 400, np.pi), off)
+    lib = capi.load_library()
+    hits = np.empty((90, 2))
+    m01 = free.astype(np.uint8)
+    pose = np.array([[sensor.x, sensor.y, sensor.theta]])
+    capi.check(lib.slam_fake_lidar_scan(0, capi.ptr(m01), m01.shape[0], m01.shape[1], capi.ptr(pose), 1, 0.0, np.pi, 500.0, 90,
+                                        capi.ptr(hits)))
+    step = np.pi / 90
+    scan = [(i * step - np.pi / 2,
+             float(np.sqrt((hits[i, 1] - sensor.y) ** 2 + (hits[i, 0] - sensor.x) ** 2)) if hits[i, 0] != -1 else 500.0)
+            for i in range(90)]
+    mcl = sa.MCL(25, (1600, 900), seed=seed)
+    for _ in range(iters):
+        mcl.predict(sa.Odometry(2.5, 0.02, 0.02), [0.0005, 0.0005, 0.01, 0.01])
+        mcl.update(scan, 5.0, 500.0, off)
+    f = mcl.filter
+    x, y, th = f.poses()
+    ref = np.stack([x, y, th, f.weights()], 1).view(np.uint64)
+    assert parts.shape == (25, 4) and np.array_equal(parts, ref)
+    ap = f.average_pose()
+    assert np.allclose(avg, [ap.x, ap.y, ap.theta], rtol=1e-12)
+    best = f.map_of(0)
+    rows, cols, mh = next(ln for ln in out if ln.startswith("MAP")).split()[1:]
+    assert (int(rows), int(cols)) == best.shape
+    hh = 0  # the same multiplicative hash of the best particle's canvas as the C++ program prints
+    for v in best.ravel().tolist():
+        hh = (hh * 1099511628211 + v) & 0xFFFFFFFFFFFFFFFF
+    assert int(mh, 16) == hh
+    f.close()
