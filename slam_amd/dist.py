@@ -52,6 +52,7 @@ class ShardedFilter:
         self.group = group
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self._gathered = backend.new_gather_buffer(self.world)
+        self._stage = None
 
     def predict(self, odom, alphas):
         self.b.predict(odom, alphas)
@@ -60,8 +61,13 @@ class ShardedFilter:
         self.b.update_weights(angles, dists, stddev, max_dist, offset)
         local = self.b.packed_state()
         if self.world > 1:
-            # the one exchange step of the path: all-gather of [x | y | theta | w] of every shard
-            dist.all_gather_into_tensor(self._gathered, local, group=self.group)
+            # the one exchange step of the path: all-gather of [x | y | theta | w] of every shard.
+            # The library's buffer is viewed zero-copy; it is staged through a torch-allocated
+            # tensor (32 B/particle) so that RCCL only ever sees allocator-owned memory.
+            if self._stage is None:
+                self._stage = torch.empty_like(local)
+            self._stage.copy_(local)
+            dist.all_gather_into_tensor(self._gathered, self._stage, group=self.group)
         else:
             self._gathered.copy_(local)
         self.b.shard_resample(self._gathered, self.world)
