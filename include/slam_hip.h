@@ -91,6 +91,7 @@ int slam_mcl_set_map_u8(slam_mcl* h, const uint8_t* map, int32_t rows, int32_t c
 /* Particle seeding / direct state access (no reference counterpart beyond reset_particles). */
 int slam_mcl_set_poses(slam_mcl* h, const double* x, const double* y, const double* theta, int64_t first, int64_t count);
 int slam_mcl_seed_gaussian(slam_mcl* h, const double mean[3], const double sigma[3]);
+int slam_mcl_seed_uniform_free(slam_mcl* h); /* uniform over the free cells of the map, heading uniform in (-pi, pi] */
 int slam_mcl_set_weights(slam_mcl* h, const double* w, int64_t first, int64_t count);
 int slam_mcl_set_maps_u8(slam_mcl* h, const uint8_t* maps, int64_t first, int64_t count); /* SLAM mode */
 

@@ -564,6 +564,27 @@ ORC_API void orc_philox_uniforms(uint64_t seed, uint64_t step, long first, long 
     for (long k = 0; k < n; ++k) u[k] = slam_resample_uniform(seed, step, static_cast<uint64_t>(first + k));
 }
 
+// Host replay of the device seeding helpers of slam_amd/csrc/noise.h (no reference counterpart).
+ORC_API void orc_seed_uniform_free(uint64_t seed, long first, long n, const uint8_t* map, int rows, int cols, double* x,
+                                   double* y, double* th)
+{
+    for (long p = 0; p < n; ++p)
+        slam_seed_uniform_free(seed, static_cast<uint64_t>(first + p), map, rows, cols, &x[p], &y[p], &th[p]);
+}
+ORC_API void orc_seed_gaussian(uint64_t seed, long first, long n, const double* mean3, const double* sigma3, double* x,
+                               double* y, double* th)
+{
+    for (long p = 0; p < n; ++p)
+    {
+        double a, b, c, d;
+        slam_normal_pair(seed, SLAM_STREAM_SEED, 0, static_cast<uint64_t>(first + p), 0, &a, &b);
+        slam_normal_pair(seed, SLAM_STREAM_SEED, 0, static_cast<uint64_t>(first + p), 1, &c, &d);
+        x[p] = mean3[0] + a * sigma3[0];
+        y[p] = mean3[1] + b * sigma3[1];
+        th[p] = mean3[2] + c * sigma3[2];
+    }
+}
+
 // slam/mcl.cpp:157-203 probabilistic_fitness_selection (selection only; map cloning is a memcpy).
 // order = 0: the reference's sequential running sum (:170-176).  order = 1: canonical blocked order.
 // canon[k] are canonical uniforms; cutoff = canon * sum (uniform_real_distribution(0, sum)).

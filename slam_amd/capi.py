@@ -63,6 +63,7 @@ SYMBOLS = {
     "slam_mcl_set_map_u8": (ctypes.c_int, [_P, _P, _I32, _I32]),
     "slam_mcl_set_poses": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64]),
     "slam_mcl_seed_gaussian": (ctypes.c_int, [_P, _P, _P]),
+    "slam_mcl_seed_uniform_free": (ctypes.c_int, [_P]),
     "slam_mcl_set_weights": (ctypes.c_int, [_P, _P, _I64, _I64]),
     "slam_mcl_set_maps_u8": (ctypes.c_int, [_P, _P, _I64, _I64]),
     "slam_mcl_set_noise": (ctypes.c_int, [_P, _P, _P]),

@@ -592,6 +592,16 @@ __global__ void __launch_bounds__(256) k_seed_gaussian(int64_t n, double* x, dou
     w[p] = vw;
 }
 
+__global__ void __launch_bounds__(256) k_seed_uniform_free(int64_t n, double* x, double* y, double* th, double* w,
+                                                           const uint8_t* map, int rows, int cols, uint64_t seed,
+                                                           uint64_t global_first, double vw)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    slam_seed_uniform_free(seed, global_first + (uint64_t)p, map, rows, cols, &x[p], &y[p], &th[p]);
+    w[p] = vw;
+}
+
 // slam/util.cpp:66-85 average_pose: per-block partial sums (fixed tree), finished on the host.
 __global__ void __launch_bounds__(256) k_pose_partials(int64_t n, const double* x, const double* y, const double* th,
                                                        double* partial /* 4 per block */)

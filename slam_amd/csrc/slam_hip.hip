@@ -672,6 +672,18 @@ SLAM_API int slam_mcl_seed_gaussian(slam_mcl* h, const double mean[3], const dou
     return finish(h);
 }
 
+SLAM_API int slam_mcl_seed_uniform_free(slam_mcl* h)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_LOCALIZATION || !h->have_map)
+        return fail(SLAM_ERR_STATE, "seed_uniform_free needs localization mode and a map");
+    hipLaunchKernelGGL(slamk::k_seed_uniform_free, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->y,
+                       h->th, h->w, h->grid, h->rows, h->cols, h->prm.seed, (uint64_t)h->prm.global_first,
+                       1.0 / (double)h->prm.global_n);
+    return finish(h);
+}
+
 SLAM_API int slam_mcl_set_maps_u8(slam_mcl* h, const uint8_t* maps, int64_t first, int64_t count)
 {
     int rc = check_handle(h);

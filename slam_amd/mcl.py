@@ -95,6 +95,9 @@ class Filter:
         m, s = f64(mean), f64(sigma)
         check(self.lib.slam_mcl_seed_gaussian(self._h, ptr(m), ptr(s)), self.lib)
 
+    def seed_uniform_free(self):
+        check(self.lib.slam_mcl_seed_uniform_free(self._h), self.lib)
+
     def set_noise(self, unit_normals=None, canonical_uniforms=None):
         z = f64(unit_normals) if unit_normals is not None else None
         u = f64(canonical_uniforms) if canonical_uniforms is not None else None

@@ -130,6 +130,21 @@ def philox_uniforms(seed, step, first, n):
     return u
 
 
+def seed_uniform_free(seed, first, n, grid):
+    g = np.ascontiguousarray(grid, dtype=np.uint8)
+    x, y, th = np.empty(n), np.empty(n), np.empty(n)
+    lib().orc_seed_uniform_free(ctypes.c_uint64(seed), ctypes.c_long(first), ctypes.c_long(n), _p(g), g.shape[0], g.shape[1],
+                                _p(x), _p(y), _p(th))
+    return x, y, th
+
+
+def seed_gaussian(seed, first, n, mean, sigma):
+    x, y, th = np.empty(n), np.empty(n), np.empty(n)
+    lib().orc_seed_gaussian(ctypes.c_uint64(seed), ctypes.c_long(first), ctypes.c_long(n), _p(_f(mean)), _p(_f(sigma)),
+                            _p(x), _p(y), _p(th))
+    return x, y, th
+
+
 def resample(w, canon, order=ORDER_REFERENCE, resampler=0):
     w, canon = _f(w), _f(canon)
     N = w.size

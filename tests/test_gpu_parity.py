@@ -493,3 +493,70 @@ def test_sharded_filter_matches_single_handle(sa, shards):
     ow, _ = orc.update_weights(ox, oy, oth, g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET)
     idx, _, _ = orc.resample(ow, orc.philox_uniforms(seed, 0, 0, N), orc.ORDER_BLOCKED)
     assert_bits(sf.b.f.poses()[0], ox[idx], "ShardedFilter world=1")
+
+
+# ---- BASELINE configs[2] and [4] at reduced particle counts: synthetic grids, long ranges, seeding ----
+def test_seeding_matches_host_replay(sa):
+    from slam_amd import synth
+
+    g = synth.make_grid(1024)
+    N, seed = 5000, 0xFACE
+    f = sa.Filter(N, *g.shape, seed=seed)
+    f.set_map(g)
+    f.seed_uniform_free()
+    x, y, th = f.poses()
+    ox, oy, oth = orc.seed_uniform_free(seed, 0, N, g)
+    assert_bits(x, ox, "x"), assert_bits(y, oy, "y"), assert_bits(th, oth, "theta")
+    i, j = (g.shape[0] - y - 1).astype(int), x.astype(int)
+    assert np.all(g[i, j] >= 128) and th.min() > -np.pi - 1e-12 and th.max() <= np.pi
+    assert np.unique(i * g.shape[1] + j).size > 0.98 * N       # spread over the free space
+    f.seed_gaussian([500.0, 400.0, 0.3], [25.0, 25.0, 0.2])
+    gx, gy, gth = orc.seed_gaussian(seed, 0, N, [500.0, 400.0, 0.3], [25.0, 25.0, 0.2])
+    x, y, th = f.poses()
+    assert_bits(x, gx, "x"), assert_bits(y, gy, "y"), assert_bits(th, gth, "theta")
+    assert_bits(f.weights(), np.full(N, 1.0 / N), "weights")
+    f.close()
+
+
+@pytest.mark.parametrize("size,N,B,zmax,stddev,uniform", [(8192, 1536, 1080, 500.0, 0.5, False), (16384, 1024, 720, 4000.0, 0.5, True)])
+def test_large_synthetic_grids(sa, size, N, B, zmax, stddev, uniform):
+    from slam_amd import synth
+
+    g = synth.make_grid(size)
+    free01 = (g >= 128).astype(np.uint8)
+    rng = np.random.default_rng(size)
+    free_cells = np.argwhere(g[size // 4:size // 4 + 64, size // 4:size // 4 + 2000] >= 128)
+    ci, cj = free_cells[len(free_cells) // 2]
+    true = [float(cj + size // 4) + 0.5, float(size - 1 - (ci + size // 4)) + 0.5, 0.7]
+    lib = sa.capi.load_library()
+    sensor = orc.sensor_position(true, OFFSET, orc.DET)
+    hits = np.empty((B, 2))
+    sa.capi.check(lib.slam_fake_lidar_scan(0, sa.capi.ptr(free01), size, size, sa.capi.ptr(np.ascontiguousarray(sensor[None])), 1,
+                                           0.0, 2 * np.pi, zmax, B, sa.capi.ptr(hits)))
+    ang, dist = orc.hits_to_scan(hits, sensor, 0.0, 2 * np.pi, zmax)
+    seed = 0x5EED0000 + size
+    fast = sa.Filter(N, size, size, seed=seed, raycaster=sa.capi.RAYCAST_FAST_PARTICLE_LANES)
+    beam = sa.Filter(N, size, size, seed=seed, raycaster=sa.capi.RAYCAST_FAST_BEAM_LANES)
+    for f in (fast, beam):
+        f.set_map(g)
+        if uniform:
+            f.seed_uniform_free()
+        else:
+            f.seed_gaussian(true, [25.0, 25.0, 0.2])
+        f.predict(ODOM, ALPHAS)
+        f.record_hits(True)
+        f.update_weights(ang, dist, stddev, zmax, OFFSET)
+    assert_bits(fast.weights(), beam.weights(), "two kernel shapes")
+    x, y, th = fast.poses()
+    sub = rng.choice(N, 48, replace=False)
+    ow, oxy, ocell, _ = orc.update_weights(x[sub], y[sub], th[sub], g, ang, dist, stddev, zmax, OFFSET, want_hits=True, math=orc.DET)
+    hxy, hcell = fast.hits()
+    assert np.array_equal(hcell[sub], ocell) and (ocell >= 0).any()
+    assert_bits(hxy[sub], oxy, "hit positions")
+    assert_bits(fast.weights()[sub], ow, "weights")
+    fast.resample()
+    w = fast.prefix()  # running sum and selection stay consistent at this size
+    idx = fast.last_indices()
+    assert idx.min() >= 0 and idx.max() < N
+    for f in (fast, beam):
+        f.close()
