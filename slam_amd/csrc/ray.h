@@ -132,9 +132,13 @@ DM_HD void ray_walk(uint8_t* map, int rows, int cols, double sx, double sy, doub
 // fl(v + d) = v + inc for the constant inc = d rounded to the u grid, PROVIDED d is not an exact
 // tie (an odd multiple of u/2; then round-half-even makes the increment depend on the parity of
 // v/u).  slam_axis_setup computes inc with the add-and-subtract-a-big-constant rounding trick and
-// the number `rem` of further adds that provably stay inside the binade (with margin).  Ties,
+// the number `rem` of further adds that provably stay inside the binade (with margin).
+// A tie d = (j + 1/2) u: round-half-even makes fl(v + d) an EVEN multiple of u whatever v was, so
+// from an even v/u on the increment is constant again, the even one of j*u and (j+1)*u, and that is
+// the value the rounding trick yields (C/u is even).  Only an odd v/u needs one real add first.
 // |v| < 4, zeros, subnormals and non-finite values get rem = 0: such a stretch is walked with real
-// adds, which are always right.
+// adds, which are always right.  (With 64 rays per wavefront and an 11-bit residual, one wavefront
+// in thirty holds a tie: walking those sample by sample cost more than all other rays together.)
 struct slam_axis
 {
     double v;    // accumulated coordinate of the current sample
@@ -154,7 +158,8 @@ DM_HD void slam_axis_setup(slam_axis* a, double d)
     const double r = (d + C) - C;                                   // exact difference
     const double t = dm_fabs(d - r);                                // exact residual, <= u/2
     const double half_ulp = dm_from_bits((uint64_t)(e - 53) << 52);  // u/2 = 2^(E-53)
-    if (!(dm_fabs(d) <= 1.0) || t == half_ulp) return;              // tie: no constant increment
+    if (!(dm_fabs(d) <= 1.0)) return;
+    if (t == half_ulp && (b & 1)) return;  // tie from an odd v/u: one real add makes it even
     a->inc = r;
     if (r == 0.0)
     {
@@ -172,15 +177,15 @@ DM_HD void slam_axis_setup(slam_axis* a, double d)
     a->rem = (int)(q * 0.99999f);
 }
 
-// One real add; re-derives inc/rem when the add left the binade.
+// One real add; re-derives inc/rem when the add left the binade or no constant increment was known.
 DM_HD void slam_axis_real_add(slam_axis* a, double d)
 {
     const double nv = a->v + d;
     const bool crossed = (dm_bits(nv) >> 52) != (dm_bits(a->v) >> 52);
     a->v = nv;
-    if (crossed)
+    if (crossed || a->rem == 0)
         slam_axis_setup(a, d);
-    else if (a->rem > 0)
+    else
         a->rem -= 1;
 }
 
@@ -224,8 +229,29 @@ DM_HD void slam_advance(slam_axis* X, slam_axis* Y, double dx, double dy, int m)
 // it without a bounds test, and "e == 0" means "hit or left the grid" (told apart afterwards).
 // k_safe = max(0, floor(zmax) - 1): for samples k <= k_safe the distance test of
 // slam/raycast.cpp:216 cannot fire (k^2 <= zmax^2 - 2 zmax + 1).
-DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
-                      double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
+//
+// The search is split into start / step / tail (one lookup per step) so that kernels can schedule
+// the pieces themselves.
+enum
+{
+    SLAM_RAY_SEARCH = 0,  // call slam_ray_step again
+    SLAM_RAY_TAIL = 1,    // sample k_safe reached: finish with slam_ray_tail
+    SLAM_RAY_DONE = 2     // result is final
+};
+
+struct slam_ray_state
+{
+    slam_axis X, Y;   // current sample
+    int rem, rem0;    // samples the fma path may still take / value at the last synchronisation
+    int left;         // samples left before k_safe (as of the last synchronisation)
+    unsigned e;       // clearance at the current sample
+    unsigned sc;      // 16.16 fixed point 0.9999 / max(|dx|,|dy|)
+    int i, j;         // cell of the current sample
+    int phase;
+};
+
+DM_HD void slam_ray_start(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
+                          int k_safe, slam_ray_state* st, slam_ray_result* res, unsigned* reads)
 {
     res->hx = -1.0;
     res->hy = -1.0;
@@ -245,6 +271,7 @@ DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double s
         e = Ep[org + i * pitch + j];
         if (reads) ++*reads;
     }
+    st->phase = SLAM_RAY_SEARCH;
     if (e == 0 && left > 0)
     {
         // start cell occupied or outside the grid: samples still inside it are skipped by the
@@ -259,97 +286,128 @@ DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double s
         } while (i == ci0 && j == cj0 && left > 0);
         if (i != ci0 || j != cj0)
         {
-            if (!slam_in_bounds(rows, cols, i, j)) return;  // slam/raycast.cpp:176
-            e = Ep[org + i * pitch + j];
-            if (reads) ++*reads;
-            if (e == 0)
-            {  // slam/raycast.cpp:183-189
-                res->hx = x;
-                res->hy = y;
-                res->hcell = i * cols + j;
-                return;
-            }
-        }
-    }
-    if (left > 0)
-    {
-        // (x, y) is an in-bounds sample with clearance e >= 1
-        slam_axis X = {x, 0.0, 0}, Y = {y, 0.0, 0};
-        slam_axis_setup(&X, dx);
-        slam_axis_setup(&Y, dy);
-        const float adx = (float)dm_fabs(dx), ady = (float)dm_fabs(dy);
-        // samples to advance = 1 + floor((e-1) * 0.9999 / max(|dx|,|dy|)), in 16.16 fixed point
-        const unsigned sc = (unsigned)(0.9999f * 65536.0f * slam_rcpf(adx > ady ? adx : ady));
-        const unsigned bias = 65536u - sc;
-        int rem = X.rem < Y.rem ? X.rem : Y.rem;  // samples the fma path may still take
-        if (rem > left) rem = left;
-        int rem0 = rem;
-        for (;;)
-        {
-            // advance m samples (any m' <= m would be legal too): one fma per axis ...
-            const int m = (int)((e * sc + bias) >> 16);
-            int t = m < rem ? m : rem;
-            rem -= t;
-            double tf = (double)t;
-            X.v = dm_fma(tf, X.inc, X.v);  // exact, see slam_axis
-            Y.v = dm_fma(tf, Y.inc, Y.v);
-            bool last = false;
-            if (t < m)
+            if (!slam_in_bounds(rows, cols, i, j))
+                st->phase = SLAM_RAY_DONE;  // slam/raycast.cpp:176
+            else
             {
-                // ... unless a binade edge, a tie stretch, |coordinate| < 4 or the end of the
-                // distance-safe range is in the way: one real add per axis, then jump on
-                X.rem -= rem0;
-                Y.rem -= rem0;
-                left -= rem0;
-                if (left > 0)
-                {
-                    slam_axis_real_add(&X, dx);
-                    slam_axis_real_add(&Y, dy);
-                    left -= 1;
-                    rem = X.rem < Y.rem ? X.rem : Y.rem;
-                    if (rem > left) rem = left;
-                    rem0 = rem;
-                    t = m - t - 1;
-                    t = t < rem ? t : rem;
-                    rem -= t;
-                    tf = (double)t;
-                    X.v = dm_fma(tf, X.inc, X.v);
-                    Y.v = dm_fma(tf, Y.inc, Y.v);
-                }
-                else
-                {
-                    rem0 = 0;
-                    last = true;  // this sample is k_safe: test it, then continue with the literal loop
-                }
-            }
-            slam_cell_of(rows, X.v, Y.v, &i, &j);
-#ifdef SLAM_RAY_DEBUG
-            if (i < -2 || i > rows + 1 || j < -2 || j > cols + 1) __builtin_trap();  // frame guarantee violated
-#endif
-            e = Ep[org + i * pitch + j];
-            if (reads) ++*reads;
-            if (e == 0)
-            {
-                if (slam_in_bounds(rows, cols, i, j))
+                e = Ep[org + i * pitch + j];
+                if (reads) ++*reads;
+                if (e == 0)
                 {  // slam/raycast.cpp:183-189
-                    res->hx = X.v;
-                    res->hy = Y.v;
+                    res->hx = x;
+                    res->hy = y;
                     res->hcell = i * cols + j;
+                    st->phase = SLAM_RAY_DONE;
                 }
-                return;  // otherwise slam/raycast.cpp:176
             }
-            if (last) break;
         }
-        x = X.v;
-        y = Y.v;
     }
-    // tail: the literal loop from sample k_safe on (dedupe against the previous sample's cell,
-    // bounds, hit, distance limit).
-    int pi = i, pj = j;
+    st->X.v = x;
+    st->Y.v = y;
+    st->i = i;
+    st->j = j;
+    st->e = e;
+    st->left = left;
+    st->rem = st->rem0 = 0;
+    st->sc = 0;
+    st->X.inc = st->Y.inc = 0.0;
+    st->X.rem = st->Y.rem = 0;
+    if (st->phase == SLAM_RAY_DONE) return;
+    if (left <= 0)
+    {
+        st->phase = SLAM_RAY_TAIL;
+        return;
+    }
+    // (x, y) is an in-bounds sample with clearance e >= 1
+    slam_axis_setup(&st->X, dx);
+    slam_axis_setup(&st->Y, dy);
+    const float adx = (float)dm_fabs(dx), ady = (float)dm_fabs(dy);
+    // samples to advance = 1 + floor((e-1) * 0.9999 / max(|dx|,|dy|)), in 16.16 fixed point
+    st->sc = (unsigned)(0.9999f * 65536.0f * slam_rcpf(adx > ady ? adx : ady));
+    int rem = st->X.rem < st->Y.rem ? st->X.rem : st->Y.rem;
+    if (rem > left) rem = left;
+    st->rem = st->rem0 = rem;
+}
+
+// One lookup: advance as far as the clearance of the current sample allows, read the clearance there.
+DM_HD void slam_ray_step(const uint8_t* Ep, int pitch, int rows, int cols, double dx, double dy, slam_ray_state* st,
+                         slam_ray_result* res, unsigned* reads)
+{
+    const int org = 2 * pitch + 2;
+    // advance m samples (any m' <= m would be legal too): one fma per axis ...
+    const int m = (int)((st->e * st->sc + (65536u - st->sc)) >> 16);
+    int t = m < st->rem ? m : st->rem;
+    st->rem -= t;
+    double tf = (double)t;
+    st->X.v = dm_fma(tf, st->X.inc, st->X.v);  // exact, see slam_axis
+    st->Y.v = dm_fma(tf, st->Y.inc, st->Y.v);
+    bool last = false;
+    if (t < m)
+    {
+        // ... unless a binade edge, a tie stretch, |coordinate| < 4 or the end of the
+        // distance-safe range is in the way: one real add per axis, then jump on
+        st->X.rem -= st->rem0;
+        st->Y.rem -= st->rem0;
+        st->left -= st->rem0;
+        if (st->left > 0)
+        {
+            slam_axis_real_add(&st->X, dx);
+            slam_axis_real_add(&st->Y, dy);
+            st->left -= 1;
+            int rem = st->X.rem < st->Y.rem ? st->X.rem : st->Y.rem;
+            if (rem > st->left) rem = st->left;
+            st->rem0 = rem;
+            t = m - t - 1;
+            t = t < rem ? t : rem;
+            st->rem = rem - t;
+            tf = (double)t;
+            st->X.v = dm_fma(tf, st->X.inc, st->X.v);
+            st->Y.v = dm_fma(tf, st->Y.inc, st->Y.v);
+        }
+        else
+        {
+            st->rem0 = 0;
+            last = true;  // this sample is k_safe: test it, then continue with the literal loop
+        }
+    }
+    int i, j;
+    slam_cell_of(rows, st->X.v, st->Y.v, &i, &j);
+#ifdef SLAM_RAY_DEBUG
+    if (i < -2 || i > rows + 1 || j < -2 || j > cols + 1) __builtin_trap();  // frame guarantee violated
+#endif
+    const unsigned e = Ep[org + i * pitch + j];
+    if (reads) ++*reads;
+    st->i = i;
+    st->j = j;
+    st->e = e;
+    if (e == 0)
+    {
+        if (slam_in_bounds(rows, cols, i, j))
+        {  // slam/raycast.cpp:183-189
+            res->hx = st->X.v;
+            res->hy = st->Y.v;
+            res->hcell = i * cols + j;
+        }
+        st->phase = SLAM_RAY_DONE;  // otherwise slam/raycast.cpp:176
+    }
+    else if (last)
+        st->phase = SLAM_RAY_TAIL;
+}
+
+// The literal loop from sample k_safe on (dedupe against the previous sample's cell, bounds, hit,
+// distance limit).
+DM_HD void slam_ray_tail(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
+                         double zmax2, slam_ray_state* st, slam_ray_result* res, unsigned* reads)
+{
+    const int org = 2 * pitch + 2;
+    double x = st->X.v, y = st->Y.v;
+    int pi = st->i, pj = st->j;
+    st->phase = SLAM_RAY_DONE;
     for (int it = 0; it < 16; ++it)
     {
         x += dx;
         y += dy;
+        int i, j;
         slam_cell_of(rows, x, y, &i, &j);
         if (i == pi && j == pj) continue;
         if (!slam_in_bounds(rows, cols, i, j)) return;
@@ -366,6 +424,15 @@ DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double s
         pi = i;
         pj = j;
     }
+}
+
+DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
+                      double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
+{
+    slam_ray_state st;
+    slam_ray_start(Ep, pitch, rows, cols, sx, sy, dx, dy, k_safe, &st, res, reads);
+    while (st.phase == SLAM_RAY_SEARCH) slam_ray_step(Ep, pitch, rows, cols, dx, dy, &st, res, reads);
+    if (st.phase == SLAM_RAY_TAIL) slam_ray_tail(Ep, pitch, rows, cols, sx, sy, dx, dy, zmax2, &st, res, reads);
 }
 
 // ------------------------------------------------------------------------------------------------

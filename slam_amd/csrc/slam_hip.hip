@@ -321,6 +321,8 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             if (want < 1) want = 1;
             if (want > B) want = B;
             a.seg_beams = (int)cdiv(B, want);
+            static const int seg_env = getenv("SLAM_PL_SEG") ? atoi(getenv("SLAM_PL_SEG")) : 0;
+            if (seg_env > 0) a.seg_beams = seg_env < B ? seg_env : B;
             a.nseg = (int)cdiv(B, a.seg_beams);
             const dim3 grid((unsigned)cdiv(a.npblocks * a.nseg, 4));
             static const int pl_waves = getenv("SLAM_PL_WAVES") ? atoi(getenv("SLAM_PL_WAVES")) : 6;

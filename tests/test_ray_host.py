@@ -56,6 +56,16 @@ def test_exact_jumps_equal_repeated_addition(hh):
         dy = -(2 * int(rng.integers(2 ** 50, 2 ** 52)) + 1) * 2.0 ** -53
         bad, _ = advance_bad(hh, rng.uniform(1, 2), rng.uniform(2, 4), dx, dy, 300, rng.integers(1, 20, size=8))
         assert bad == 0
+    tie_jumped = 0
+    for t in range(3000):  # ties in the binades a 4096-cell map uses: one real add, then constant increments again
+        ex, ey = int(rng.integers(10, 13)), int(rng.integers(10, 13))
+        dx = np.ldexp(2 * int(rng.integers(2 ** (51 - ex), 2 ** (52 - ex))) + 1, ex - 53)  # odd multiple of ulp(2^ex)/2, < 1
+        dy = -np.ldexp(2 * int(rng.integers(2 ** (51 - ey), 2 ** (52 - ey))) + 1, ey - 53)
+        x0, y0 = rng.uniform(2.0 ** ex, 2.0 ** (ex + 1) - 400), rng.uniform(2.0 ** ey + 400, 2.0 ** (ey + 1))
+        bad, js = advance_bad(hh, x0, y0, dx, dy, 300, rng.integers(1, 40, size=8))
+        assert bad == 0, (x0, y0, dx, dy)
+        tie_jumped += js
+    assert tie_jumped > 0.9 * 3000 * 300, "ties must not fall back to sample-by-sample adds"
     for dx, dy in [(0.0, 1.0), (1.0, 0.0), (6.123233995736766e-17, 1.0), (-1.0, 1e-300), (2.0 ** -60, -1.0)]:
         bad, _ = advance_bad(hh, 500.25, 0.75, dx, dy, 800, [1, 7, 64, 255, 3])
         assert bad == 0
