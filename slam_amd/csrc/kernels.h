@@ -85,6 +85,7 @@ struct WeightArgs
     int64_t p_first;            // first particle of this launch
     int64_t npblocks;           // 64-particle blocks in this launch
     int nseg, seg_beams;        // beams are cut into nseg segments of seg_beams
+    const int32_t* order;       // optional: slot -> particle (pose-coherent order, see k_order_keys)
 };
 
 // K2a.  VARIANT 0: ray_fast_L on the clearance grid.  VARIANT 1: literal walk on the raw map
@@ -157,6 +158,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     const int seg = (int)(item - pb * a.nseg);
     int64_t p = a.p_first + pb * 64 + lane;
     if (p >= a.n) p = a.n - 1;  // padding lanes repeat the last particle; their values are never summed
+    if (a.order) p = a.order[p];
     const double px = a.x[p], py = a.y[p], pth = a.th[p];
     double s0, c0;
     dm_sincos(pth + a.stheta, &s0, &c0);
@@ -183,12 +185,49 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     }
 }
 
+// Pose-coherent order for k_rays_pl.  The weight of a particle does not depend on which lane
+// computes it, so the particles are dealt to wavefronts by a key of (heading bucket, 2-cell tile):
+// the 64 rays a wavefront walks together then start from the same few cells with headings within
+// 1/256 turn, take nearly the same number of lookups and touch the same cache lines.  Keys wrap
+// (12 bits per axis): far-apart particles that alias only cost coherence, never correctness.
+__global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, const double* y, const double* th,
+                                                    int mode, uint32_t* keys, int32_t* ident)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const unsigned tx = ((unsigned)slam_f2i(x[p]) >> 1) & 0xfffu;
+    const unsigned ty = ((unsigned)slam_f2i(y[p]) >> 1) & 0xfffu;
+    // 1/(2 pi) to float precision is plenty for a bucket index
+    const unsigned tb = (unsigned)slam_f2i(th[p] * 40.74366543152521 + 1024.0) & 0xffu;
+    unsigned k;
+    if (mode == 2)
+        k = (ty << 20) | (tx << 8) | tb;
+    else if (mode == 3)
+    {  // Morton order of the tiles below the heading bucket
+        unsigned a = tx, b = ty;
+        a = (a | (a << 8)) & 0x00ff00ffu;
+        a = (a | (a << 4)) & 0x0f0f0f0fu;
+        a = (a | (a << 2)) & 0x33333333u;
+        a = (a | (a << 1)) & 0x55555555u;
+        b = (b | (b << 8)) & 0x00ff00ffu;
+        b = (b | (b << 4)) & 0x0f0f0f0fu;
+        b = (b | (b << 2)) & 0x33333333u;
+        b = (b | (b << 1)) & 0x55555555u;
+        k = (tb << 24) | (a | (b << 1));
+    }
+    else
+        k = (tb << 24) | (ty << 12) | tx;
+    keys[p] = k;
+    ident[p] = (int32_t)p;
+}
+
 // weight = exp(sum_b lw[b]) with the sum taken in beam order (slam/mcl.cpp:67-75).
 __global__ void __launch_bounds__(256) k_sum_lw(WeightArgs a)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // particle within this launch
-    const int64_t p = a.p_first + q;
+    int64_t p = a.p_first + q;
     if (q >= a.npblocks * 64 || p >= a.n) return;
+    if (a.order) p = a.order[p];
     const double* slab = a.lw + (size_t)(q >> 6) * (size_t)a.B * 64 + (q & 63);
     double acc = 0.0;
     int b = 0;

@@ -41,6 +41,15 @@ DM_HD float slam_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 DM_HD float slam_rcpf(float x) { return 1.0f / x; }
 #endif
 
+// i * pitch for -2 <= i < 2^23 and pitch < 2^23 (a full-rate 24-bit multiply on the device)
+#if defined(__HIP_DEVICE_COMPILE__)
+DM_HD int slam_mul24(int a, int b) { return __mul24(a, b); }
+DM_HD unsigned slam_mul24(unsigned a, unsigned b) { return __umul24(a, b); }
+#else
+DM_HD int slam_mul24(int a, int b) { return a * b; }
+DM_HD unsigned slam_mul24(unsigned a, unsigned b) { return a * b; }
+#endif
+
 DM_HD void slam_cell_of(int rows, double x, double y, int* i, int* j)
 {
     *i = slam_f2i(((double)rows - y) - 1.0);
@@ -148,33 +157,32 @@ struct slam_axis
 
 DM_HD void slam_axis_setup(slam_axis* a, double d)
 {
+    // straight-line code (every lane of a wavefront runs it once per ray): all quantities are
+    // computed, the validity conditions select at the end
     const uint64_t b = dm_bits(a->v);
     const int e = (int)((b >> 52) & 0x7ff);
-    a->rem = 0;
-    a->inc = 0.0;
-    if (e < 0x401 || e > 0x433) return;  // |v| < 4 or |v| >= 2^53 (or inf/nan): real adds only
     // C = 1.5 * 2^E: d + C lies in [2^E, 2^(E+1)) for |d| <= 1, so fl(d + C) is d rounded to the u grid
     const double C = dm_from_bits(((uint64_t)e << 52) | 0x0008000000000000ull);
-    const double r = (d + C) - C;                                   // exact difference
-    const double t = dm_fabs(d - r);                                // exact residual, <= u/2
-    const double half_ulp = dm_from_bits((uint64_t)(e - 53) << 52);  // u/2 = 2^(E-53)
-    if (!(dm_fabs(d) <= 1.0)) return;
-    if (t == half_ulp && (b & 1)) return;  // tie from an odd v/u: one real add makes it even
-    a->inc = r;
-    if (r == 0.0)
-    {
-        a->rem = 1 << 20;  // fl(v + d) == v for every add
-        return;
-    }
+    const double r = (d + C) - C;                                              // exact difference
+    const double t = dm_fabs(d - r);                                           // exact residual, <= u/2
+    const double half_ulp = dm_from_bits((uint64_t)(unsigned)(e - 53) << 52);  // u/2 = 2^(E-53)
     const double av = dm_fabs(a->v);
     const double lo = dm_from_bits((uint64_t)e << 52);
     const bool grow = (r > 0.0) == ((b >> 63) == 0);
-    const double num = grow ? (lo + lo) - av : av - lo;  // exact distance to the binade edge
+    const double num = grow ? (lo + lo) - av : av - lo;   // exact distance to the binade edge
     float q = (float)num * slam_rcpf((float)dm_fabs(r));  // |r| >= u >= 2^-50: no float underflow
+    q = q > 0.0f ? q : 0.0f;                              // (also NaN -> 0)
     q = q < 1.0e6f ? q : 1.0e6f;
     // adds that land strictly inside the binade: ceil(num/|r|) - 1; the factor covers the float
     // rounding of q (relative 3e-7) and makes an exact integer quotient round down
-    a->rem = (int)(q * 0.99999f);
+    int rem = (int)(q * 0.99999f);
+    if (r == 0.0) rem = 1 << 20;  // fl(v + d) == v for every add
+    // |v| < 4 or |v| >= 2^53 (or inf/nan), |d| > 1, a tie from an odd v/u (one real add makes it
+    // even): real adds only
+    const bool ok = ((unsigned)(e - 0x401) <= (unsigned)(0x433 - 0x401)) & (dm_fabs(d) <= 1.0) &
+                    !((t == half_ulp) & ((b & 1) != 0));
+    a->inc = ok ? r : 0.0;
+    a->rem = ok ? rem : 0;
 }
 
 // One real add; re-derives inc/rem when the add left the binade or no constant increment was known.
@@ -230,48 +238,27 @@ DM_HD void slam_advance(slam_axis* X, slam_axis* Y, double dx, double dy, int m)
 // k_safe = max(0, floor(zmax) - 1): for samples k <= k_safe the distance test of
 // slam/raycast.cpp:216 cannot fire (k^2 <= zmax^2 - 2 zmax + 1).
 //
-// The search is split into start / step / tail (one lookup per step) so that kernels can schedule
-// the pieces themselves.
-enum
-{
-    SLAM_RAY_SEARCH = 0,  // call slam_ray_step again
-    SLAM_RAY_TAIL = 1,    // sample k_safe reached: finish with slam_ray_tail
-    SLAM_RAY_DONE = 2     // result is final
-};
-
-struct slam_ray_state
-{
-    slam_axis X, Y;   // current sample
-    int rem, rem0;    // samples the fma path may still take / value at the last synchronisation
-    int left;         // samples left before k_safe (as of the last synchronisation)
-    unsigned e;       // clearance at the current sample
-    unsigned sc;      // 16.16 fixed point 0.9999 / max(|dx|,|dy|)
-    int i, j;         // cell of the current sample
-    int phase;
-};
-
-DM_HD void slam_ray_start(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
-                          int k_safe, slam_ray_state* st, slam_ray_result* res, unsigned* reads)
+DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
+                      double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
 {
     res->hx = -1.0;
     res->hy = -1.0;
     res->hcell = -1;
-    const int org = 2 * pitch + 2;
+    const int org = 2 * pitch + 2;  // cell (0,0)
+    const double rows_d = (double)rows;
     // accumulated rounding stays far below the distance margin only for moderate coordinates;
     // anything farther out starts (and stays) outside every supported grid: literal loop only.
     int left = (dm_fabs(sx) < 1048576.0 && dm_fabs(sy) < 1048576.0) ? k_safe : 0;
     double x = sx, y = sy;
-    int i, j;
-    slam_cell_of(rows, x, y, &i, &j);
+    int i = slam_f2i((rows_d - y) - 1.0), j = slam_f2i(x);
     // sample 0 (the start cell) is never tested (slam/raycast.cpp:153-157); its clearance still
     // tells how far the first jump may go.
     unsigned e = 0;
     if (slam_in_bounds(rows, cols, i, j))
     {
-        e = Ep[org + i * pitch + j];
+        e = Ep[(unsigned)(slam_mul24(i, pitch) + j + org)];
         if (reads) ++*reads;
     }
-    st->phase = SLAM_RAY_SEARCH;
     if (e == 0 && left > 0)
     {
         // start cell occupied or outside the grid: samples still inside it are skipped by the
@@ -282,137 +269,116 @@ DM_HD void slam_ray_start(const uint8_t* Ep, int pitch, int rows, int cols, doub
             x += dx;
             y += dy;
             --left;
-            slam_cell_of(rows, x, y, &i, &j);
+            i = slam_f2i((rows_d - y) - 1.0);
+            j = slam_f2i(x);
         } while (i == ci0 && j == cj0 && left > 0);
         if (i != ci0 || j != cj0)
         {
-            if (!slam_in_bounds(rows, cols, i, j))
-                st->phase = SLAM_RAY_DONE;  // slam/raycast.cpp:176
-            else
-            {
-                e = Ep[org + i * pitch + j];
-                if (reads) ++*reads;
-                if (e == 0)
-                {  // slam/raycast.cpp:183-189
-                    res->hx = x;
-                    res->hy = y;
-                    res->hcell = i * cols + j;
-                    st->phase = SLAM_RAY_DONE;
-                }
+            if (!slam_in_bounds(rows, cols, i, j)) return;  // slam/raycast.cpp:176
+            e = Ep[(unsigned)(slam_mul24(i, pitch) + j + org)];
+            if (reads) ++*reads;
+            if (e == 0)
+            {  // slam/raycast.cpp:183-189
+                res->hx = x;
+                res->hy = y;
+                res->hcell = i * cols + j;
+                return;
             }
         }
     }
-    st->X.v = x;
-    st->Y.v = y;
-    st->i = i;
-    st->j = j;
-    st->e = e;
-    st->left = left;
-    st->rem = st->rem0 = 0;
-    st->sc = 0;
-    st->X.inc = st->Y.inc = 0.0;
-    st->X.rem = st->Y.rem = 0;
-    if (st->phase == SLAM_RAY_DONE) return;
-    if (left <= 0)
+    if (left > 0)
     {
-        st->phase = SLAM_RAY_TAIL;
-        return;
-    }
-    // (x, y) is an in-bounds sample with clearance e >= 1
-    slam_axis_setup(&st->X, dx);
-    slam_axis_setup(&st->Y, dy);
-    const float adx = (float)dm_fabs(dx), ady = (float)dm_fabs(dy);
-    // samples to advance = 1 + floor((e-1) * 0.9999 / max(|dx|,|dy|)), in 16.16 fixed point
-    st->sc = (unsigned)(0.9999f * 65536.0f * slam_rcpf(adx > ady ? adx : ady));
-    int rem = st->X.rem < st->Y.rem ? st->X.rem : st->Y.rem;
-    if (rem > left) rem = left;
-    st->rem = st->rem0 = rem;
-}
-
-// One lookup: advance as far as the clearance of the current sample allows, read the clearance there.
-DM_HD void slam_ray_step(const uint8_t* Ep, int pitch, int rows, int cols, double dx, double dy, slam_ray_state* st,
-                         slam_ray_result* res, unsigned* reads)
-{
-    const int org = 2 * pitch + 2;
-    // advance m samples (any m' <= m would be legal too): one fma per axis ...
-    const int m = (int)((st->e * st->sc + (65536u - st->sc)) >> 16);
-    int t = m < st->rem ? m : st->rem;
-    st->rem -= t;
-    double tf = (double)t;
-    st->X.v = dm_fma(tf, st->X.inc, st->X.v);  // exact, see slam_axis
-    st->Y.v = dm_fma(tf, st->Y.inc, st->Y.v);
-    bool last = false;
-    if (t < m)
-    {
-        // ... unless a binade edge, a tie stretch, |coordinate| < 4 or the end of the
-        // distance-safe range is in the way: one real add per axis, then jump on
-        st->X.rem -= st->rem0;
-        st->Y.rem -= st->rem0;
-        st->left -= st->rem0;
-        if (st->left > 0)
+        // (x, y) is an in-bounds sample with clearance e >= 1
+        slam_axis X = {x, 0.0, 0}, Y = {y, 0.0, 0};
+        slam_axis_setup(&X, dx);
+        slam_axis_setup(&Y, dy);
+        const float adx = (float)dm_fabs(dx), ady = (float)dm_fabs(dy);
+        // samples to advance = 1 + floor((e-1) * 0.9999 / max(|dx|,|dy|)); the 1e-4 margin covers the
+        // float roundings (2^-23 relative on a value < 400), the single fused multiply-add makes
+        // host and device agree
+        const float sc = 0.9999f * slam_rcpf(adx > ady ? adx : ady);
+        const float sc1 = 1.0f - sc;
+        int budget = X.rem < Y.rem ? X.rem : Y.rem;  // samples the fma path may take before a re-synchronisation
+        if (budget > left) budget = left;
+        int budget0 = budget;
+        double incx = X.inc, incy = Y.inc;
+        x = X.v;
+        y = Y.v;
+        for (;;)
         {
-            slam_axis_real_add(&st->X, dx);
-            slam_axis_real_add(&st->Y, dy);
-            st->left -= 1;
-            int rem = st->X.rem < st->Y.rem ? st->X.rem : st->Y.rem;
-            if (rem > st->left) rem = st->left;
-            st->rem0 = rem;
-            t = m - t - 1;
-            t = t < rem ? t : rem;
-            st->rem = rem - t;
-            tf = (double)t;
-            st->X.v = dm_fma(tf, st->X.inc, st->X.v);
-            st->Y.v = dm_fma(tf, st->Y.inc, st->Y.v);
-        }
-        else
-        {
-            st->rem0 = 0;
-            last = true;  // this sample is k_safe: test it, then continue with the literal loop
-        }
-    }
-    int i, j;
-    slam_cell_of(rows, st->X.v, st->Y.v, &i, &j);
+            // advance m samples (any m' <= m would be legal too): one fma per axis ...
+            const int m = (int)__builtin_fmaf((float)e, sc, sc1);
+            int t = m < budget ? m : budget;
+            budget -= t;
+            double tf = (double)t;
+            x = dm_fma(tf, incx, x);  // exact, see slam_axis
+            y = dm_fma(tf, incy, y);
+            bool last = false;
+            if (__builtin_expect(t < m, 0))
+            {
+                // ... unless a binade edge, |coordinate| < 4 or the end of the distance-safe range
+                // is in the way: one real add per axis, then jump on
+                X.v = x;
+                Y.v = y;
+                X.rem -= budget0;
+                Y.rem -= budget0;
+                left -= budget0;
+                if (left > 0)
+                {
+                    slam_axis_real_add(&X, dx);
+                    slam_axis_real_add(&Y, dy);
+                    left -= 1;
+                    budget = X.rem < Y.rem ? X.rem : Y.rem;
+                    if (budget > left) budget = left;
+                    budget0 = budget;
+                    t = m - t - 1;
+                    t = t < budget ? t : budget;
+                    budget -= t;
+                    tf = (double)t;
+                    incx = X.inc;
+                    incy = Y.inc;
+                    x = dm_fma(tf, incx, X.v);
+                    y = dm_fma(tf, incy, Y.v);
+                }
+                else
+                {
+                    budget0 = 0;
+                    last = true;  // this sample is k_safe: test it, then continue with the literal loop
+                }
+            }
+            i = slam_f2i((rows_d - y) - 1.0);
+            j = slam_f2i(x);
 #ifdef SLAM_RAY_DEBUG
-    if (i < -2 || i > rows + 1 || j < -2 || j > cols + 1) __builtin_trap();  // frame guarantee violated
+            if (i < -2 || i > rows + 1 || j < -2 || j > cols + 1) __builtin_trap();  // frame guarantee violated
 #endif
-    const unsigned e = Ep[org + i * pitch + j];
-    if (reads) ++*reads;
-    st->i = i;
-    st->j = j;
-    st->e = e;
-    if (e == 0)
-    {
-        if (slam_in_bounds(rows, cols, i, j))
-        {  // slam/raycast.cpp:183-189
-            res->hx = st->X.v;
-            res->hy = st->Y.v;
-            res->hcell = i * cols + j;
+            e = Ep[(unsigned)(slam_mul24(i, pitch) + j + org)];
+            if (reads) ++*reads;
+            if (e == 0 || last) break;
         }
-        st->phase = SLAM_RAY_DONE;  // otherwise slam/raycast.cpp:176
+        if (e == 0)
+        {
+            if (slam_in_bounds(rows, cols, i, j))
+            {  // slam/raycast.cpp:183-189
+                res->hx = x;
+                res->hy = y;
+                res->hcell = i * cols + j;
+            }
+            return;  // otherwise slam/raycast.cpp:176
+        }
     }
-    else if (last)
-        st->phase = SLAM_RAY_TAIL;
-}
-
-// The literal loop from sample k_safe on (dedupe against the previous sample's cell, bounds, hit,
-// distance limit).
-DM_HD void slam_ray_tail(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
-                         double zmax2, slam_ray_state* st, slam_ray_result* res, unsigned* reads)
-{
-    const int org = 2 * pitch + 2;
-    double x = st->X.v, y = st->Y.v;
-    int pi = st->i, pj = st->j;
-    st->phase = SLAM_RAY_DONE;
+    // the literal loop from sample k_safe on (dedupe against the previous sample's cell, bounds,
+    // hit, distance limit)
+    int pi = i, pj = j;
     for (int it = 0; it < 16; ++it)
     {
         x += dx;
         y += dy;
-        int i, j;
-        slam_cell_of(rows, x, y, &i, &j);
+        i = slam_f2i((rows_d - y) - 1.0);
+        j = slam_f2i(x);
         if (i == pi && j == pj) continue;
         if (!slam_in_bounds(rows, cols, i, j)) return;
         if (reads) ++*reads;
-        if (Ep[org + i * pitch + j] == 0)
+        if (Ep[(unsigned)(slam_mul24(i, pitch) + j + org)] == 0)
         {
             res->hx = x;
             res->hy = y;
@@ -424,15 +390,6 @@ DM_HD void slam_ray_tail(const uint8_t* Ep, int pitch, int rows, int cols, doubl
         pi = i;
         pj = j;
     }
-}
-
-DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
-                      double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
-{
-    slam_ray_state st;
-    slam_ray_start(Ep, pitch, rows, cols, sx, sy, dx, dy, k_safe, &st, res, reads);
-    while (st.phase == SLAM_RAY_SEARCH) slam_ray_step(Ep, pitch, rows, cols, dx, dy, &st, res, reads);
-    if (st.phase == SLAM_RAY_TAIL) slam_ray_tail(Ep, pitch, rows, cols, sx, sy, dx, dy, zmax2, &st, res, reads);
 }
 
 // ------------------------------------------------------------------------------------------------

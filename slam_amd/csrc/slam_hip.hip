@@ -105,6 +105,10 @@ struct slam_mcl
     double* partials = nullptr;
     double* lw = nullptr;  // scratch of the particle-lane weight kernels
     size_t lw_cap = 0;     // doubles
+    uint32_t *okeys = nullptr, *okeys2 = nullptr;  // pose-coherent order of the particle-lane kernels
+    int32_t *oident = nullptr, *order = nullptr;
+    void* osort_tmp = nullptr;
+    size_t osort_tmp_bytes = 0;
     bool profile = false;
     std::vector<TimedSpan> spans;
     double acc_ms[G_COUNT] = {0, 0, 0, 0, 0};
@@ -261,6 +265,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.p_first = 0;
     a.npblocks = 0;
     a.nseg = a.seg_beams = 0;
+    a.order = nullptr;
     // slam/mcl.cpp:80-86 with the int-returning squared distance of slam/util.h:138-146
     {
         const double ddx = 0 - off[0], ddy = 0 - off[1];
@@ -312,6 +317,30 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             h->lw_cap = need;
         }
         a.lw = h->lw;
+        static const int order_mode = getenv("SLAM_PL_ORDER") ? atoi(getenv("SLAM_PL_ORDER")) : 3;
+        if (order_mode > 0)
+        {
+            if (!h->okeys)
+            {
+                int rc;
+                if ((rc = dev_alloc(&h->okeys, h->n)) || (rc = dev_alloc(&h->okeys2, h->n)) ||
+                    (rc = dev_alloc(&h->oident, h->n)) || (rc = dev_alloc(&h->order, h->n)))
+                    return rc;
+                size_t bytes = 0;
+                HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0,
+                                                 32, h->stream));
+                uint8_t* tmp = nullptr;
+                if ((rc = dev_alloc(&tmp, bytes ? bytes : 16))) return rc;
+                h->osort_tmp = tmp;
+                h->osort_tmp_bytes = bytes;
+            }
+            hipLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x,
+                               h->y, h->th, order_mode, h->okeys, h->oident);
+            size_t bytes = h->osort_tmp_bytes;
+            HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, 32,
+                                             h->stream));
+            a.order = h->order;
+        }
         for (int64_t pb0 = 0; pb0 < pblocks_all; pb0 += pb_per_launch)
         {
             a.p_first = pb0 * 64;
@@ -469,7 +498,8 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
     void* ptrs[] = {h->state, h->state2,
                     h->grid,  h->clr,    h->maps, h->maps2,    h->luts,         h->scan_dev,
                     h->inj_normals, h->inj_uniforms, h->idx, h->perm, h->slots, h->src,   h->keys, h->keys2,
-                    h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw};
+                    h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
+                    h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (size_t l = 0; l < h->lvl_s.size(); ++l)
