@@ -29,6 +29,42 @@ def pmc_stats(db):
     return "\n".join(out)
 
 
+def weights_traffic(base):
+    """HBM bytes per launch of the weighting pass from the FETCH_SIZE / WRITE_SIZE passes (KB per
+    dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    import json
+
+    def avg(db, counter, like):
+        cur = sqlite3.connect(db).cursor()
+        cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+        kcol = "kernel_name" if "kernel_name" in cols else "name"
+        r = cur.execute(f"select avg(value) from counters_collection where counter_name=? and {kcol} like ?",
+                        (counter, like)).fetchone()
+        return float(r[0]) if r and r[0] is not None else None
+
+    f = glob.glob(os.path.join(base, "pmc_fetch", "*_results.db"))
+    w = glob.glob(os.path.join(base, "pmc_l2", "*_results.db"))
+    if not f or not w:
+        return None
+    out = {"source": "profiles/rocprof_%s.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                     "bench.py --steps 10 --warmup 3)" % os.path.basename(base).replace("prof_", ""),
+           "units": "FETCH_SIZE and WRITE_SIZE are KB per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes "
+                    "for gfx950 (it tallies 128-B requests at 64 B); byte-gather reads of k_rays_pl are an uncalibrated "
+                    "access width",
+           "kernels": {}}
+    total = 0.0
+    for k in ("k_rays_pl", "k_sum_lw"):
+        fk, wk = avg(f[0], "FETCH_SIZE", f"%{k}%"), avg(w[0], "WRITE_SIZE", f"%{k}%")
+        if fk is None or wk is None:
+            return None
+        b = 2.0 * fk * 1024.0 + wk * 1024.0
+        out["kernels"][k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes": b}
+        total += b
+    out["hbm_bytes_per_launch"] = total
+    json.dump(out, open(os.path.join("profiles", "pmc_weights_kernel.json"), "w"), indent=1)
+    return out
+
+
 def main(tag):
     base = os.path.join("gpurun_out", f"prof_{tag}")
     lines = [f"# rocprofv3 summary, tag {tag} (command: see profiles/run_profile.sh)"]
@@ -42,6 +78,7 @@ def main(tag):
     text = "\n".join(lines) + "\n"
     open(os.path.join("profiles", f"rocprof_{tag}.txt"), "w").write(text)
     print(text)
+    print(weights_traffic(base))
 
 
 if __name__ == "__main__":

@@ -153,9 +153,11 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t pb = item / a.nseg;
-    if (pb >= a.npblocks) return;  // whole wavefront
-    const int seg = (int)(item - pb * a.nseg);
+    // segment-major: the four wavefronts of a workgroup walk the same beams for neighbouring
+    // (pose-sorted) particle blocks, i.e. the same map cells at about the same time
+    const int seg = (int)(item / a.npblocks);
+    if (seg >= a.nseg) return;  // whole wavefront
+    const int64_t pb = item - (int64_t)seg * a.npblocks;
     int64_t p = a.p_first + pb * 64 + lane;
     if (p >= a.n) p = a.n - 1;  // padding lanes repeat the last particle; their values are never summed
     if (a.order) p = a.order[p];
