@@ -158,6 +158,29 @@ int slam_mcl_device_state_get(slam_mcl* h, slam_mcl_device_state* out);
  * handle with n_particles = global_n and SLAM_SORT_NONE, for any number of shards.
  * Requires localization mode, SLAM_SORT_NONE, SLAM_PREFIX_BLOCKED. */
 int slam_mcl_shard_resample(slam_mcl* h, const double* gathered_state_dev, int32_t n_shards);
+
+/* Sharded resampling in SLAM mode (per-particle canvases, slam/mcl.cpp:147-155,205-227): the
+ * selected particles' canvases live on the shard that owns the source, so the step has an exchange
+ * of whole canvases between the two halves:
+ *   1. slam_mcl_shard_select: as slam_mcl_shard_resample for poses and weights; the global source
+ *      index of every local slot is left in idx_dev (slam_mcl_device_maps_get), canvases untouched.
+ *   2. the caller tells every owner which of its canvases are wanted, the owners pack them with
+ *      slam_mcl_pack_maps (out_dev[c] = canvas local_idx_dev[c], map_stride bytes each) and the
+ *      packed canvases travel (all-to-all over RCCL, slam_amd/dist.py);
+ *   3. slam_mcl_shard_clone_maps: canvas of local slot k = pool_dev[pos_dev[k]] (map_stride bytes
+ *      each), which completes the resample.
+ * predict / update_weights before step 3 would see stale canvases; update_weights refuses. */
+int slam_mcl_shard_select(slam_mcl* h, const double* gathered_state_dev, int32_t n_shards);
+int slam_mcl_pack_maps(slam_mcl* h, const int32_t* local_idx_dev, int64_t count, uint8_t* out_dev);
+int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, const int32_t* pos_dev);
+typedef struct slam_mcl_device_maps
+{
+    uint8_t* maps_dev;       /* n_particles canvases, map_stride bytes apart (rows*cols valid bytes each) */
+    const int32_t* idx_dev;  /* global source index per local slot, from the last select */
+    int64_t map_stride;
+    int64_t n_particles;
+} slam_mcl_device_maps;
+int slam_mcl_device_maps_get(slam_mcl* h, slam_mcl_device_maps* out);
 int slam_mcl_synchronize(slam_mcl* h);
 
 /* FakeLidar::scan (slam/fake_lidar.cpp:15-33) + raycast<int> (slam/raycast.cpp:100-141), batched

@@ -42,6 +42,15 @@ class Params(ctypes.Structure):
     ]
 
 
+class DeviceMaps(ctypes.Structure):
+    _fields_ = [
+        ("maps_dev", ctypes.c_void_p),
+        ("idx_dev", ctypes.c_void_p),
+        ("map_stride", ctypes.c_int64),
+        ("n_particles", ctypes.c_int64),
+    ]
+
+
 class DeviceState(ctypes.Structure):
     _fields_ = [
         ("state_dev", ctypes.c_void_p),
@@ -72,6 +81,10 @@ SYMBOLS = {
     "slam_mcl_update_weights": (ctypes.c_int, [_P, _P, _P, _I32, _D, _D, _P]),
     "slam_mcl_resample": (ctypes.c_int, [_P]),
     "slam_mcl_shard_resample": (ctypes.c_int, [_P, _P, _I32]),
+    "slam_mcl_shard_select": (ctypes.c_int, [_P, _P, _I32]),
+    "slam_mcl_pack_maps": (ctypes.c_int, [_P, _P, _I64, _P]),
+    "slam_mcl_shard_clone_maps": (ctypes.c_int, [_P, _P, _P]),
+    "slam_mcl_device_maps_get": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_poses": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64]),
     "slam_mcl_get_weights": (ctypes.c_int, [_P, _P, _I64, _I64]),
     "slam_mcl_get_map_u8": (ctypes.c_int, [_P, _I64, _P]),

@@ -594,15 +594,16 @@ __global__ void __launch_bounds__(256) k_gather(StateView view, const int32_t* i
     src[p] = s;
 }
 
-// slam/mcl.cpp:147-155: deep copy of each selected particle's map.  grid = (chunks, particles).
+// slam/mcl.cpp:147-155: deep copy of each selected particle's map.  grid = (particles, chunks).
+// Also packs maps for the sharded exchange (dst slot p <- src map src[p]).
 __global__ void __launch_bounds__(256) k_clone_maps(const uint8_t* maps, uint8_t* maps2, const int32_t* src,
                                                     size_t stride)
 {
-    const size_t p = blockIdx.y;
+    const size_t p = blockIdx.x;
     const uint4* from = reinterpret_cast<const uint4*>(maps + stride * (size_t)src[p]);
     uint4* to = reinterpret_cast<uint4*>(maps2 + stride * p);
     const size_t n16 = stride / 16;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n16; t += (size_t)gridDim.x * blockDim.x)
+    for (size_t t = (size_t)blockIdx.y * blockDim.x + threadIdx.x; t < n16; t += (size_t)gridDim.y * blockDim.x)
         to[t] = from[t];
 }
 

@@ -79,6 +79,7 @@ struct slam_mcl
     uint8_t *maps = nullptr, *maps2 = nullptr;   // SLAM: per-particle canvases
     uint8_t* luts = nullptr;
     bool have_map = false;
+    bool maps_pending = false;  // SLAM-mode shard: poses resampled, canvases not yet (shard_select done)
     // scan
     int Bcap = 0;
     double* scan_dev = nullptr;  // [angle | dist^2 | sqrt(dist^2)], Bcap doubles each (packed at B)
@@ -231,6 +232,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         return fail(SLAM_ERR_ARG, "scanner_offset: null or non-finite");
     const bool slam_mode = h->prm.mode == SLAM_MODE_SLAM;
     if (!slam_mode && !h->have_map) return fail(SLAM_ERR_STATE, "localization mode: call slam_mcl_set_map_u8 first");
+    if (h->maps_pending) return fail(SLAM_ERR_STATE, "canvases of the last slam_mcl_shard_select are still pending (slam_mcl_shard_clone_maps)");
     if (h->record_hits)
     {
         const size_t need = (size_t)h->n * B;
@@ -412,16 +414,26 @@ int do_prefix(slam_mcl* h, const slamk::StateView& view)
 }
 
 // `gathered`: packed states of all shards ([n_shards][4][n]); nullptr = this handle alone.
-int do_resample(slam_mcl* h, const double* gathered, int n_shards)
+void launch_clone(slam_mcl* h, const uint8_t* from, uint8_t* to, const int32_t* src, int64_t count)
+{
+    const unsigned chunks = (unsigned)std::min<size_t>(cdiv((int64_t)(h->map_stride / 16), 256), 64);
+    hipLaunchKernelGGL(slamk::k_clone_maps, dim3((unsigned)count, chunks), dim3(256), 0, h->stream, from, to, src,
+                       h->map_stride);
+}
+
+// clone_local = false: SLAM-mode shards; the caller exchanges the canvases and finishes with
+// slam_mcl_shard_clone_maps.
+int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_local = true)
 {
     const bool injected = h->prm.noise == SLAM_NOISE_INJECTED;
     if (injected && !h->have_uniforms) return fail(SLAM_ERR_STATE, "injected noise: no uniforms set for this update");
     const int64_t n = h->n;
     if ((int64_t)n_shards * n != h->n_glob)
         return fail(SLAM_ERR_STATE, "resample: shards * n_particles != global_n (sharded handles must use slam_mcl_shard_resample)");
-    if (n_shards > 1 && (h->prm.sort != SLAM_SORT_NONE || h->prm.prefix_order != SLAM_PREFIX_BLOCKED ||
-                         h->prm.mode != SLAM_MODE_LOCALIZATION))
-        return fail(SLAM_ERR_STATE, "sharded resampling needs localization mode, SLAM_SORT_NONE and SLAM_PREFIX_BLOCKED");
+    if (n_shards > 1 && (h->prm.sort != SLAM_SORT_NONE || h->prm.prefix_order != SLAM_PREFIX_BLOCKED))
+        return fail(SLAM_ERR_STATE, "sharded resampling needs SLAM_SORT_NONE and SLAM_PREFIX_BLOCKED");
+    if (n_shards > 1 && h->prm.mode == SLAM_MODE_SLAM && clone_local)
+        return fail(SLAM_ERR_STATE, "SLAM-mode shards: use slam_mcl_shard_select + slam_mcl_shard_clone_maps");
     slamk::StateView view;
     view.base = gathered ? gathered : h->state;
     view.n_loc = n;
@@ -461,12 +473,10 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards)
     }
     std::swap(h->state, h->state2);
     h->bind();
-    if (h->prm.mode == SLAM_MODE_SLAM)
+    if (h->prm.mode == SLAM_MODE_SLAM && clone_local)
     {
         slam_mcl::Span span(h, G_CLONE);
-        const unsigned chunks = (unsigned)std::min<size_t>(cdiv((int64_t)(h->map_stride / 16), 256), 64);
-        hipLaunchKernelGGL(slamk::k_clone_maps, dim3(chunks, (unsigned)n), dim3(256), 0, h->stream, h->maps, h->maps2,
-                           h->src, h->map_stride);
+        launch_clone(h, h->maps, h->maps2, h->src, n);
         HIPCHK(hipGetLastError());
         std::swap(h->maps, h->maps2);
     }
@@ -816,6 +826,63 @@ SLAM_API int slam_mcl_shard_resample(slam_mcl* h, const double* gathered_state_d
     if (h->n % 64) return fail(SLAM_ERR_STATE, "sharded resampling needs n_particles % 64 == 0 on every shard");
     if ((rc = do_resample(h, gathered_state_dev, n_shards))) return rc;
     return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_shard_select(slam_mcl* h, const double* gathered_state_dev, int32_t n_shards)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!gathered_state_dev || n_shards < 1) return fail(SLAM_ERR_ARG, "shard_select: null buffer or n_shards < 1");
+    if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "shard_select is the SLAM-mode form of shard_resample");
+    if (h->prm.sort != SLAM_SORT_NONE || h->prm.prefix_order != SLAM_PREFIX_BLOCKED)
+        return fail(SLAM_ERR_STATE, "sharded resampling needs SLAM_SORT_NONE and SLAM_PREFIX_BLOCKED");
+    if (h->n % 64) return fail(SLAM_ERR_STATE, "sharded resampling needs n_particles % 64 == 0 on every shard");
+    if ((rc = do_resample(h, gathered_state_dev, n_shards, false))) return rc;
+    h->maps_pending = true;
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_pack_maps(slam_mcl* h, const int32_t* local_idx_dev, int64_t count, uint8_t* out_dev)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "pack_maps: SLAM mode only");
+    if (count < 0 || count > 2147483647LL || (count > 0 && (!local_idx_dev || !out_dev)))
+        return fail(SLAM_ERR_ARG, "pack_maps: bad count or null pointer");
+    if (count > 0)
+    {
+        slam_mcl::Span span(h, G_CLONE);
+        launch_clone(h, h->maps, out_dev, local_idx_dev, count);
+        HIPCHK(hipGetLastError());
+    }
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, const int32_t* pos_dev)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "shard_clone_maps: SLAM mode only");
+    if (!h->maps_pending) return fail(SLAM_ERR_STATE, "shard_clone_maps: no slam_mcl_shard_select pending");
+    if (!pool_dev || !pos_dev) return fail(SLAM_ERR_ARG, "shard_clone_maps: null pointer");
+    {
+        slam_mcl::Span span(h, G_CLONE);
+        launch_clone(h, pool_dev, h->maps2, pos_dev, h->n);
+        HIPCHK(hipGetLastError());
+    }
+    std::swap(h->maps, h->maps2);
+    h->maps_pending = false;
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_device_maps_get(slam_mcl* h, slam_mcl_device_maps* out)
+{
+    if (!h || !out) return fail(SLAM_ERR_ARG, "null");
+    out->maps_dev = h->maps;
+    out->idx_dev = h->idx;
+    out->map_stride = (int64_t)h->map_stride;
+    out->n_particles = h->n;
+    return SLAM_OK;
 }
 
 SLAM_API int slam_mcl_update(slam_mcl* h, const double* angles, const double* dists, int32_t n_beams, double stddev,

@@ -4,6 +4,8 @@ all-gather of the packed per-shard state (32 B per particle) over RCCL/xGMI (`nc
 rank then rebuilds the running sum of all weights in the canonical blocked order, draws its own
 output slots and copies the selected particles out of the gathered buffer.  The result is
 bit-identical for any number of ranks (tests/test_dist_cpu.py, tests/test_gpu_parity.py).
+In SLAM mode (per-particle canvases) the selected canvases are exchanged as well: one all-to-all of
+whole canvases, each distinct (source, destination rank) pair travelling once.
 
 The per-shard compute is behind a small backend interface so that the collective logic can be
 exercised with `gloo` on CPU tensors in the tests; the product backend is HipShard (libslam_hip.so).
@@ -18,12 +20,14 @@ from .mcl import Filter
 class HipShard:
     """Shard backend on one MI355X through the C ABI."""
 
-    def __init__(self, n_local, rows, cols, rank, world, device, seed, stream=None, **kw):
-        self.f = Filter(n_local, rows, cols, mode=capi.MODE_LOCALIZATION, device=device, seed=seed,
+    def __init__(self, n_local, rows, cols, rank, world, device, seed, stream=None, mode=capi.MODE_LOCALIZATION, **kw):
+        self.f = Filter(n_local, rows, cols, mode=mode, device=device, seed=seed,
                         sort=capi.SORT_NONE, prefix_order=capi.PREFIX_BLOCKED, global_first=rank * n_local,
                         global_n=world * n_local, stream=stream, **kw)
         self.n_local = n_local
         self.device = torch.device(f"cuda:{device}")
+        self.slam_mode = mode == capi.MODE_SLAM
+        self.map_stride = int(self.f.device_maps().map_stride) if self.slam_mode else 0
 
     def set_map(self, grid):
         self.f.set_map(grid)
@@ -42,6 +46,21 @@ class HipShard:
 
     def shard_resample(self, gathered, world):
         self.f.shard_resample(gathered.data_ptr(), world)
+
+    # SLAM mode: the three local pieces around the canvas exchange
+    def shard_select(self, gathered, world):
+        self.f.shard_select(gathered.data_ptr(), world)
+        return self.f.index_tensor().to(torch.int64)
+
+    def pack_maps(self, local_idx):
+        idx32 = local_idx.to(torch.int32).contiguous()
+        out = torch.empty((idx32.numel(), self.map_stride), dtype=torch.uint8, device=self.device)
+        self.f.pack_maps(idx32.data_ptr(), idx32.numel(), out.data_ptr())
+        return out
+
+    def clone_maps(self, pool, pos):
+        pos32 = pos.to(torch.int32).contiguous()
+        self.f.shard_clone_maps(pool.data_ptr(), pos32.data_ptr())
 
 
 class ShardedFilter:
@@ -70,4 +89,29 @@ class ShardedFilter:
             dist.all_gather_into_tensor(self._gathered, self._stage, group=self.group)
         else:
             self._gathered.copy_(local)
-        self.b.shard_resample(self._gathered, self.world)
+        if not getattr(self.b, "slam_mode", False):
+            self.b.shard_resample(self._gathered, self.world)
+            return
+        # SLAM mode (per-particle canvases): the selected canvases live with their owners.
+        #   want  = the distinct global sources of my slots, sorted -> grouped by owner
+        #   each owner learns which of its canvases every rank wants (two small all-to-alls),
+        #   packs them once per requester and the canvases travel in ONE all-to-all;
+        #   my slot k then clones row searchsorted(want, idx[k]) of what arrived.
+        idx = self.b.shard_select(self._gathered, self.world)
+        want = torch.unique(idx)
+        n_loc = self.b.n_local
+        owner = torch.div(want, n_loc, rounding_mode="floor")
+        n_want = torch.bincount(owner, minlength=self.world)
+        local_ids = want - owner * n_loc
+        if self.world > 1:
+            n_req = torch.empty_like(n_want)
+            dist.all_to_all_single(n_req, n_want, group=self.group)
+            want_split, req_split = n_want.tolist(), n_req.tolist()
+            req = torch.empty(sum(req_split), dtype=local_ids.dtype, device=local_ids.device)
+            dist.all_to_all_single(req, local_ids, req_split, want_split, group=self.group)
+            send = self.b.pack_maps(req)
+            pool = torch.empty((want.numel(), send.shape[1]), dtype=torch.uint8, device=send.device)
+            dist.all_to_all_single(pool, send, want_split, req_split, group=self.group)
+        else:
+            pool = self.b.pack_maps(local_ids)
+        self.b.clone_maps(pool, torch.searchsorted(want, idx))

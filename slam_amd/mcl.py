@@ -128,6 +128,35 @@ class Filter:
         """gathered_state_ptr: device address of the all-gathered packed states ([n_shards][4][n])."""
         check(self.lib.slam_mcl_shard_resample(self._h, ctypes.c_void_p(int(gathered_state_ptr)), n_shards), self.lib)
 
+    def shard_select(self, gathered_state_ptr, n_shards):
+        """SLAM-mode shards, step 1: poses and weights resampled, canvases pending (see include/slam_hip.h)."""
+        check(self.lib.slam_mcl_shard_select(self._h, ctypes.c_void_p(int(gathered_state_ptr)), n_shards), self.lib)
+
+    def pack_maps(self, local_idx_ptr, count, out_ptr):
+        check(self.lib.slam_mcl_pack_maps(self._h, ctypes.c_void_p(int(local_idx_ptr)), count,
+                                          ctypes.c_void_p(int(out_ptr))), self.lib)
+
+    def shard_clone_maps(self, pool_ptr, pos_ptr):
+        check(self.lib.slam_mcl_shard_clone_maps(self._h, ctypes.c_void_p(int(pool_ptr)), ctypes.c_void_p(int(pos_ptr))),
+              self.lib)
+
+    def device_maps(self):
+        dm = capi.DeviceMaps()
+        check(self.lib.slam_mcl_device_maps_get(self._h, ctypes.byref(dm)), self.lib)
+        return dm
+
+    def index_tensor(self):
+        """Zero-copy torch view (n,) int32 of the global source indices of the last select."""
+        import torch
+
+        dm = self.device_maps()
+
+        class _Arr:
+            __cuda_array_interface__ = {"shape": (self.n,), "typestr": "<i4", "data": (int(dm.idx_dev), False),
+                                        "version": 2, "strides": None}
+
+        return torch.as_tensor(_Arr(), device=f"cuda:{self.params.device}")
+
     def state_tensor(self):
         """Zero-copy torch view (4, n) float64 of the packed resident state [x | y | theta | weight].
         The buffer changes after every resample; call again after each update."""

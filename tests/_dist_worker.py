@@ -35,6 +35,10 @@ class OracleShard:
         self.pstep += 1
 
     def update_weights(self, angles, dists, stddev, max_dist, offset):
+        if self.slam_mode:
+            self.w, _ = orc.update_weights(self.x, self.y, self.th, self.maps, angles, dists, stddev, max_dist, offset,
+                                           slam_mode=True, math=orc.DET)
+            return
         self.w, _ = orc.update_weights(self.x, self.y, self.th, self.grid, angles, dists, stddev, max_dist, offset,
                                        math=orc.DET)
 
@@ -43,6 +47,24 @@ class OracleShard:
 
     def new_gather_buffer(self, world):
         return torch.empty(world * 4 * self.n, dtype=torch.float64)
+
+    # SLAM mode (per-particle canvases): same three pieces as HipShard
+    slam_mode = False
+
+    def enable_slam(self, rows, cols):
+        self.slam_mode = True
+        self.n_local = self.n
+        self.maps = np.full((self.n, rows, cols), 128, np.uint8)  # slam/mcl.cpp:30
+
+    def shard_select(self, gathered, world):
+        self.shard_resample(gathered, world)
+        return torch.from_numpy(self.last_idx.astype(np.int64))
+
+    def pack_maps(self, local_idx):
+        return torch.from_numpy(self.maps[local_idx.numpy()].reshape(local_idx.numel(), -1).copy())
+
+    def clone_maps(self, pool, pos):
+        self.maps = pool.numpy()[pos.numpy()].reshape((self.n,) + self.maps.shape[1:]).copy()
 
     def shard_resample(self, gathered, world):
         g = gathered.numpy().reshape(world, 4, self.n)
@@ -57,8 +79,43 @@ class OracleShard:
         self.rstep += 1
 
 
+SLAM_CANVAS, SLAM_POSE, SLAM_OFFSET, SLAM_BEAMS, SLAM_ZMAX = 96, [48.0, 44.0, 0.3], [0.0, 6.0, 0.0], 24, 40.0
+
+
+def slam_room():
+    """Ground truth of the SLAM-mode case: a walled room with a pillar (1 = free)."""
+    free = np.ones((SLAM_CANVAS, SLAM_CANVAS), np.int32)
+    free[:3, :] = free[-3:, :] = free[:, :3] = free[:, -3:] = 0
+    free[60:70, 20:30] = 0
+    return free
+
+
+def main_slam(out, n_total, steps):
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_loc = n_total // world
+    rng = np.random.default_rng(6)
+    x = SLAM_POSE[0] + 2 * rng.standard_normal(n_total)
+    y = SLAM_POSE[1] + 2 * rng.standard_normal(n_total)
+    th = SLAM_POSE[2] + 0.1 * rng.standard_normal(n_total)
+    sl = slice(rank * n_loc, (rank + 1) * n_loc)
+    shard = OracleShard(n_loc, rank, world, 0x51A4, None, x[sl], y[sl], th[sl])
+    shard.enable_slam(SLAM_CANVAS, SLAM_CANVAS)
+    sf = ShardedFilter(shard, world=world)
+    ang, dscan = orc.make_scan(slam_room(), SLAM_POSE, SLAM_OFFSET, SLAM_BEAMS, max_dist=SLAM_ZMAX)
+    for _ in range(steps):
+        sf.predict([0.0, 0.5, 0.0], ALPHAS)
+        sf.update(ang, dscan, 2.0, SLAM_ZMAX, SLAM_OFFSET)
+    np.savez(os.path.join(out, f"rank{rank}.npz"), x=shard.x, y=shard.y, th=shard.th, w=shard.w, idx=shard.last_idx,
+             maps=shard.maps)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     out, n_total, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    if len(sys.argv) > 4 and sys.argv[4] == "slam":
+        return main_slam(out, n_total, steps)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     n_loc = n_total // world

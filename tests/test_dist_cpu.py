@@ -14,16 +14,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ODOM, ALPHAS, OFFSET = [2.5, 0.02, 0.02], [5e-4, 5e-4, 1e-2, 1e-2], [0.0, 30.0, 0.0]
 
 
-def run_world(tmp_path, world, n_total, steps):
-    out = tmp_path / f"w{world}"
+def run_world(tmp_path, world, n_total, steps, mode="loc"):
+    out = tmp_path / f"w{world}{mode}"
     out.mkdir()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29500 + world + os.getpid() % 200),
-           os.path.join(HERE, "_dist_worker.py"), str(out), str(n_total), str(steps)]
+           os.path.join(HERE, "_dist_worker.py"), str(out), str(n_total), str(steps), mode]
     subprocess.run(cmd, check=True, env=env, timeout=600, capture_output=True)
     parts = [np.load(out / f"rank{r}.npz") for r in range(world)]
-    return {k: np.concatenate([p[k] for p in parts]) for k in ("x", "y", "th", "w", "idx")}
+    keys = ("x", "y", "th", "w", "idx") + (("maps",) if mode == "slam" else ())
+    return {k: np.concatenate([p[k] for p in parts]) for k in keys}
 
 
 def reference_run(n_total, steps):
@@ -49,3 +50,35 @@ def test_sharded_filter_gloo_matches_unsharded(tmp_path, world):
     assert np.array_equal(got["idx"], ref["idx"])
     for k in ("x", "y", "th", "w"):
         assert np.array_equal(got[k].view(np.uint64), ref[k].view(np.uint64)), k
+
+
+def reference_run_slam(n_total, steps):
+    import _dist_worker as dw
+
+    rng = np.random.default_rng(6)
+    x = dw.SLAM_POSE[0] + 2 * rng.standard_normal(n_total)
+    y = dw.SLAM_POSE[1] + 2 * rng.standard_normal(n_total)
+    th = dw.SLAM_POSE[2] + 0.1 * rng.standard_normal(n_total)
+    maps = np.full((n_total, dw.SLAM_CANVAS, dw.SLAM_CANVAS), 128, np.uint8)
+    ang, dscan = orc.make_scan(dw.slam_room(), dw.SLAM_POSE, dw.SLAM_OFFSET, dw.SLAM_BEAMS, max_dist=dw.SLAM_ZMAX)
+    idx = None
+    for s in range(steps):
+        x, y, th = orc.predict(x, y, th, [0.0, 0.5, 0.0], ALPHAS, orc.philox_normals(0x51A4, s, 0, n_total), math=orc.DET)
+        w, _ = orc.update_weights(x, y, th, maps, ang, dscan, 2.0, dw.SLAM_ZMAX, dw.SLAM_OFFSET, slam_mode=True, math=orc.DET)
+        idx, _, _ = orc.resample(w, orc.philox_uniforms(0x51A4, s, 0, n_total), orc.ORDER_BLOCKED)
+        x, y, th, w, maps = x[idx], y[idx], th[idx], w[idx], maps[idx].copy()
+    return {"x": x, "y": y, "th": th, "w": w, "idx": idx, "maps": maps}
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_slam_mode_gloo_matches_unsharded(tmp_path, world):
+    """SLAM mode: the canvases of the selected particles cross ranks (all-to-all) and every rank ends
+    up with exactly the canvases the unsharded filter holds in those slots."""
+    n_total, steps = 128, 3
+    got = run_world(tmp_path, world, n_total, steps, mode="slam")
+    ref = reference_run_slam(n_total, steps)
+    assert np.array_equal(got["idx"], ref["idx"])
+    for k in ("x", "y", "th", "w"):
+        assert np.array_equal(got[k].view(np.uint64), ref[k].view(np.uint64)), k
+    assert np.array_equal(got["maps"], ref["maps"])
+    assert len(np.unique(ref["maps"].reshape(n_total, -1), axis=0)) > 1  # the canvases do differ

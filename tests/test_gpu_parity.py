@@ -495,6 +495,75 @@ def test_sharded_filter_matches_single_handle(sa, shards):
     assert_bits(sf.b.f.poses()[0], ox[idx], "ShardedFilter world=1")
 
 
+@pytest.mark.parametrize("shards", [2, 4])
+def test_sharded_slam_mode_matches_single_handle(sa, shards):
+    """SLAM-mode shards: select, canvas exchange (emulated here on one device: what the two small
+    all-to-alls and the canvas all-to-all of slam_amd.dist deliver), clone.  Poses, weights and every
+    canvas equal the single handle's and the oracle's."""
+    import torch
+
+    from slam_amd.dist import HipShard, ShardedFilter
+
+    rng = np.random.default_rng(41)
+    N, B, seed, rows, cols, zmax = 256, 60, 0xBEEF, 150, 200, 120.0
+    free = orc.load_map("map")
+    ang, dist = orc.make_scan(free, [400.0, 400.0, np.pi / 90], OFFSET, B, max_dist=zmax)
+    x, y, th = cloud(rng, N, cols / 2, rows / 2, sxy=4.0, sth=0.2, th0=np.pi / 2)
+    odom = [0.0, 1.5, 0.0]
+    single = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed, sort=sa.capi.SORT_NONE)
+    single.set_poses(x, y, th)
+    n_loc = N // shards
+    backs = [HipShard(n_loc, rows, cols, r, shards, 0, seed, mode=sa.capi.MODE_SLAM) for r in range(shards)]
+    for r, b in enumerate(backs):
+        b.f.set_poses(x[r * n_loc:(r + 1) * n_loc], y[r * n_loc:(r + 1) * n_loc], th[r * n_loc:(r + 1) * n_loc])
+    state, maps = (x, y, th), np.full((N, rows, cols), 128, np.uint8)
+    for step in range(3):
+        single.predict(odom, ALPHAS)
+        single.update(ang, dist, 5.0, zmax, OFFSET)
+        for b in backs:
+            b.predict(odom, ALPHAS)
+            b.update_weights(ang, dist, 5.0, zmax, OFFSET)
+        gathered = torch.cat([b.packed_state() for b in backs])
+        torch.cuda.synchronize()
+        idxs = [b.shard_select(gathered, shards) for b in backs]
+        with pytest.raises(RuntimeError):  # canvases pending: weighting must refuse
+            backs[0].update_weights(ang, dist, 5.0, zmax, OFFSET)
+        pools, wants = [], []
+        for r, b in enumerate(backs):   # requester r
+            want = torch.unique(idxs[r])
+            owner = torch.div(want, n_loc, rounding_mode="floor")
+            parts = [backs[o].pack_maps((want[owner == o] - o * n_loc)) for o in range(shards)]
+            pools.append(torch.cat(parts))
+            wants.append(want)
+        for r, b in enumerate(backs):
+            b.clone_maps(pools[r], torch.searchsorted(wants[r], idxs[r]))
+        ox, oy, oth = orc.predict(*state, odom, ALPHAS, orc.philox_normals(seed, step, 0, N), math=orc.DET)
+        ow, _ = orc.update_weights(ox, oy, oth, maps, ang, dist, 5.0, zmax, OFFSET, slam_mode=True, math=orc.DET)
+        idx, _, _ = orc.resample(ow, orc.philox_uniforms(seed, step, 0, N), orc.ORDER_BLOCKED)
+        state, maps = (ox[idx], oy[idx], oth[idx]), maps[idx].copy()
+        assert np.array_equal(single.last_indices(), idx)
+        assert np.array_equal(np.concatenate([b.f.last_indices() for b in backs]), idx)
+        for q in range(3):
+            assert_bits(np.concatenate([b.f.poses()[q] for b in backs]), state[q], f"{shards} shards")
+        assert_bits(np.concatenate([b.f.weights() for b in backs]), ow[idx], "weights")
+        for p in range(0, N, 7):
+            assert np.array_equal(single.map_of(p), maps[p]), f"single handle, canvas {p}, step {step}"
+            assert np.array_equal(backs[p // n_loc].f.map_of(p % n_loc), maps[p]), f"shard canvas {p}, step {step}"
+    assert len(np.unique(maps.reshape(N, -1), axis=0)) > 1
+    # the driver class itself with world = 1 (pack + clone through the same entry points)
+    sf = ShardedFilter(HipShard(N, rows, cols, 0, 1, 0, seed, mode=sa.capi.MODE_SLAM), world=1)
+    sf.b.f.set_poses(x, y, th)
+    m1 = np.full((N, rows, cols), 128, np.uint8)
+    sf.predict(odom, ALPHAS)
+    sf.update(ang, dist, 5.0, zmax, OFFSET)
+    ox, oy, oth = orc.predict(x, y, th, odom, ALPHAS, orc.philox_normals(seed, 0, 0, N), math=orc.DET)
+    ow, _ = orc.update_weights(ox, oy, oth, m1, ang, dist, 5.0, zmax, OFFSET, slam_mode=True, math=orc.DET)
+    idx, _, _ = orc.resample(ow, orc.philox_uniforms(seed, 0, 0, N), orc.ORDER_BLOCKED)
+    assert_bits(sf.b.f.poses()[0], ox[idx], "ShardedFilter world=1, SLAM mode")
+    for p in range(0, N, 17):
+        assert np.array_equal(sf.b.f.map_of(p), m1[idx[p]])
+
+
 # ---- BASELINE configs[2] and [4] at reduced particle counts: synthetic grids, long ranges, seeding ----
 def test_seeding_matches_host_replay(sa):
     from slam_amd import synth
