@@ -245,7 +245,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_rays_pl + k_sum_lw (raycast + beam likelihood, one weighting pass)", "kernel_avg_ms": k_avg_ms,
+                "kernel": "weighting pass = k_order_keys + radix sort + k_rays_pl + k_sum_lw (raycast + beam likelihood)", "kernel_avg_ms": k_avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes, "cells_per_ray_reference_walk": sbar,
                 "kernel_particle_beams_per_s": n_loc * B / (k_avg_ms * 1e-3),
             },
