@@ -37,6 +37,7 @@ enum { SLAM_NOISE_PHILOX = 0, SLAM_NOISE_INJECTED = 1 };
 enum { SLAM_PREFIX_BLOCKED = 0, SLAM_PREFIX_REFERENCE = 1 };
 enum { SLAM_RESAMPLE_MULTINOMIAL = 0, SLAM_RESAMPLE_SYSTEMATIC = 1 };
 enum { SLAM_SORT_FULL = 0, SLAM_SORT_NONE = 1 };
+enum { SLAM_WEIGHT_LINEAR = 0, SLAM_WEIGHT_LOG = 1 };
 enum
 {
     SLAM_RAYCAST_FAST = 0,                /* clearance-skipping search; kernel shape chosen by N */
@@ -72,7 +73,11 @@ typedef struct slam_mcl_params
     int32_t async_launch;  /* 0: predict/update* return after the stream has drained (default).
                               1: they return after enqueueing; the caller orders later work on
                               `stream` or calls slam_mcl_synchronize */
-    int32_t reserved;
+    int32_t weight_domain; /* SLAM_WEIGHT_LINEAR: weight = exp(sum_b log w_b), slam/mcl.cpp:67-75 (underflows
+                              to 0 for every particle beyond ~434 beams).
+                              SLAM_WEIGHT_LOG (opt-in, no reference counterpart): the weight column
+                              holds sum_b log w_b and the selection of slam/mcl.cpp:157-203 runs on
+                              exp(lw - max lw), max over the whole filter (all shards) */
 } slam_mcl_params;
 
 const char* slam_last_error(void);

@@ -231,7 +231,7 @@ template <class M>
 int update_inner(int start, int n, const double* x, const double* y, const double* th, unsigned char* maps,
                  size_t map_stride, int rows, int cols, int B, const double* angles, const double* dists, double stddev,
                  double max_dist, double scanner_d, double scanner_theta, double scanner_rot, bool write, double* w_out,
-                 double* hit_xy, int* hit_cell, RayStats* st)
+                 double* hit_xy, int* hit_cell, RayStats* st, bool log_domain = false)
 {
     for (int p = start; p < start + n; ++p)
     {
@@ -258,7 +258,8 @@ int update_inner(int start, int n, const double* x, const double* y, const doubl
             }
             if (hit_cell) hit_cell[static_cast<size_t>(p) * B + b] = hc;
         }
-        w_out[p] = M::exp(weight);
+        // log_domain: opt-in extension, the sum of slam/mcl.cpp:73 without the exp of :75
+        w_out[p] = log_domain ? weight : M::exp(weight);
     }
     return 0;
 }
@@ -464,6 +465,7 @@ ORC_API int orc_measurement_model_beam(uint8_t* map, int rows, int cols, double 
 // rows*cols bytes, each particle walks and updates its own (slam::MCL as written).  mode_slam = 0:
 // maps is ONE shared map, read only (SURVEY.md §8a row aL).  n_threads follows the reference's
 // slicing (contiguous N/T, remainder on the last thread); n_threads <= 1 runs inline.
+// math: bit 0 = deterministic elementary functions, bit 1 = log-domain weights (extension).
 ORC_API int orc_update_weights(int mode_slam, long N, const double* x, const double* y, const double* th,
                                uint8_t* maps, int rows, int cols, int B, const double* angles, const double* dists,
                                double stddev, double max_dist, const double* offset3, int math, int n_threads,
@@ -476,13 +478,14 @@ ORC_API int orc_update_weights(int mode_slam, long N, const double* x, const dou
     const int T = std::max(1, n_threads);
     std::vector<RayStats> st(T);
     std::vector<int> rc(T, 0);
+    const bool det = (math & 1) != 0, logd = (math & 2) != 0;
     auto run = [&](int t, long start, long n) {
-        rc[t] = math ? update_inner<DetMath>(static_cast<int>(start), static_cast<int>(n), x, y, th, maps, stride, rows,
+        rc[t] = det ? update_inner<DetMath>(static_cast<int>(start), static_cast<int>(n), x, y, th, maps, stride, rows,
+                                            cols, B, angles, dists, stddev, max_dist, sd, stheta, offset3[2], write,
+                                            w_out, hit_xy, hit_cell, &st[t], logd)
+                    : update_inner<LibmMath>(static_cast<int>(start), static_cast<int>(n), x, y, th, maps, stride, rows,
                                              cols, B, angles, dists, stddev, max_dist, sd, stheta, offset3[2], write,
-                                             w_out, hit_xy, hit_cell, &st[t])
-                     : update_inner<LibmMath>(static_cast<int>(start), static_cast<int>(n), x, y, th, maps, stride, rows,
-                                              cols, B, angles, dists, stddev, max_dist, sd, stheta, offset3[2], write,
-                                              w_out, hit_xy, hit_cell, &st[t]);
+                                             w_out, hit_xy, hit_cell, &st[t], logd);
     };
     if (T == 1)
         run(0, 0, N);
@@ -512,6 +515,15 @@ ORC_API int orc_update_weights(int mode_slam, long N, const double* x, const dou
     for (int r : rc)
         if (r) return r;
     return 0;
+}
+
+// Log-domain extension: the weights the selection of slam/mcl.cpp:157-203 runs on,
+// w'[p] = exp(lw[p] - max_q lw[q]) (1 for the best particle, no underflow of the whole set).
+ORC_API void orc_log_domain_weights(long N, const double* lw, int math, double* out)
+{
+    double m = lw[0];
+    for (long p = 1; p < N; ++p) m = lw[p] > m ? lw[p] : m;
+    for (long p = 0; p < N; ++p) out[p] = (math & 1) ? DetMath::exp(lw[p] - m) : LibmMath::exp(lw[p] - m);
 }
 
 // slam/mcl.cpp:41-47 MCL::predict with injected unit normals z[3*N].

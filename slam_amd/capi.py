@@ -6,13 +6,14 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libslam_hip.so")
+LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libslam_hip.so")  # override: experiments only
 
 MODE_LOCALIZATION, MODE_SLAM = 0, 1
 NOISE_PHILOX, NOISE_INJECTED = 0, 1
 PREFIX_BLOCKED, PREFIX_REFERENCE = 0, 1
 RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
 SORT_FULL, SORT_NONE = 0, 1
+WEIGHT_LINEAR, WEIGHT_LOG = 0, 1
 RAYCAST_FAST, RAYCAST_WALK, RAYCAST_FAST_BEAM_LANES, RAYCAST_FAST_PARTICLE_LANES = 0, 1, 2, 3
 
 
@@ -38,7 +39,7 @@ class Params(ctypes.Structure):
         ("global_n", ctypes.c_int64),
         ("stream", ctypes.c_void_p),
         ("async_launch", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("weight_domain", ctypes.c_int32),
     ]
 
 

@@ -86,6 +86,7 @@ struct WeightArgs
     int64_t npblocks;           // 64-particle blocks in this launch
     int nseg, seg_beams;        // beams are cut into nseg segments of seg_beams
     const int32_t* order;       // optional: slot -> particle (pose-coherent order, see k_order_keys)
+    int log_domain;             // SLAM_WEIGHT_LOG: store the sum of logs instead of its exp
 };
 
 // K2a.  VARIANT 0: ray_fast_L on the clearance grid.  VARIANT 1: literal walk on the raw map
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
         const int cnt = (a.B - b0) < 64 ? (a.B - b0) : 64;
         for (int l = 0; l < cnt; ++l) acc += readlane_f64(lw, l);
     }
-    if (lane == 0) a.w[p] = dm_exp(acc);
+    if (lane == 0) a.w[p] = a.log_domain ? acc : dm_exp(acc);
     if (VARIANT == 1 && a.stats)
     {
         atomicAdd(&a.stats[0], st.cells_read);
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(256) k_sum_lw(WeightArgs a)
         for (int u = 0; u < 8; ++u) acc += v[u];
     }
     for (; b < a.B; ++b) acc += slab[(size_t)b * 64];
-    a.w[p] = dm_exp(acc);
+    a.w[p] = a.log_domain ? acc : dm_exp(acc);
 }
 
 // K2b, first form: one thread per particle, beams and cells strictly in the reference's order.
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(64) k_weights_S(WeightArgs a)
             a.hit_cell[o] = r.hcell;
         }
     }
-    a.w[p] = dm_exp(acc);
+    a.w[p] = a.log_domain ? acc : dm_exp(acc);
     if (a.stats)
     {
         atomicAdd(&a.stats[0], st.cells_read);
@@ -451,7 +452,7 @@ __global__ void __launch_bounds__(256) k_weights_S_wave(WeightArgs a)
     }
     if (lane == 0)
     {
-        a.w[p] = dm_exp(acc);
+        a.w[p] = a.log_domain ? acc : dm_exp(acc);
         if (a.stats)
         {
             atomicAdd(&a.stats[0], n_read);
@@ -474,6 +475,35 @@ __device__ __forceinline__ double sv_get(const StateView& v, int q, int64_t i)
     const int64_t r = i / v.n_loc;
     const int64_t o = i - r * v.n_loc;
     return v.base[(r * 4 + q) * v.n_loc + o];
+}
+
+// SLAM_WEIGHT_LOG: maximum of the weight column of all shards (max is exact, so any reduction order
+// gives the same value), then wlin[i] = exp(lw[i] - max).
+__global__ void __launch_bounds__(256) k_max_partials(const double* a, StateView view, int64_t n, double* part)
+{
+    __shared__ double sh[256];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // -inf for the padding: every real value is finite or -inf itself
+    double v = i < n ? (a ? a[i] : sv_get(view, 3, i)) : -__builtin_inf();
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1)
+    {
+        if ((int)threadIdx.x < d)
+        {
+            const double o = sh[threadIdx.x + d];
+            if (o > sh[threadIdx.x]) sh[threadIdx.x] = o;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+__global__ void __launch_bounds__(256) k_exp_shift(StateView view, int64_t n, const double* max1, double* wlin)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    wlin[i] = dm_exp(sv_get(view, 3, i) - max1[0]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -79,6 +79,7 @@ struct slam_mcl
     uint8_t *maps = nullptr, *maps2 = nullptr;   // SLAM: per-particle canvases
     uint8_t* luts = nullptr;
     bool have_map = false;
+    double *wlin = nullptr, *wmax = nullptr;  // SLAM_WEIGHT_LOG: exp(lw - max) of all shards, max-reduction levels
     bool maps_pending = false;  // SLAM-mode shard: poses resampled, canvases not yet (shard_select done)
     // scan
     int Bcap = 0;
@@ -268,6 +269,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.npblocks = 0;
     a.nseg = a.seg_beams = 0;
     a.order = nullptr;
+    a.log_domain = h->prm.weight_domain == SLAM_WEIGHT_LOG;
     // slam/mcl.cpp:80-86 with the int-returning squared distance of slam/util.h:138-146
     {
         const double ddx = 0 - off[0], ddy = 0 - off[1];
@@ -385,16 +387,36 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
 // running sums of the weights of all shards (n_glob entries) into lvl_P[0], in the configured order
 int do_prefix(slam_mcl* h, const slamk::StateView& view)
 {
+    const double* lin = nullptr;  // SLAM_WEIGHT_LOG: the selection runs on exp(lw - max lw)
+    if (h->prm.weight_domain == SLAM_WEIGHT_LOG)
+    {
+        int64_t m = h->n_glob;
+        const double* src = nullptr;
+        double* dst = h->wmax;
+        for (;;)
+        {
+            const int64_t nb = cdiv(m, 256);
+            hipLaunchKernelGGL(slamk::k_max_partials, dim3((unsigned)nb), dim3(256), 0, h->stream, src, view, m, dst);
+            if (nb == 1) break;
+            src = dst;
+            dst += nb;
+            m = nb;
+        }
+        hipLaunchKernelGGL(slamk::k_exp_shift, dim3((unsigned)cdiv(h->n_glob, 256)), dim3(256), 0, h->stream, view,
+                           h->n_glob, dst, h->wlin);
+        HIPCHK(hipGetLastError());
+        lin = h->wlin;
+    }
     if (h->prm.prefix_order == SLAM_PREFIX_REFERENCE)
     {
         // single shard only (checked by the caller): the weight column is contiguous
-        hipLaunchKernelGGL(slamk::k_prefix_seq, dim3(1), dim3(64), 0, h->stream, view.base + 3 * view.n_loc, h->n_glob,
-                           h->lvl_P[0]);
+        hipLaunchKernelGGL(slamk::k_prefix_seq, dim3(1), dim3(64), 0, h->stream, lin ? lin : view.base + 3 * view.n_loc,
+                           h->n_glob, h->lvl_P[0]);
         HIPCHK(hipGetLastError());
         return SLAM_OK;
     }
     const int L = (int)h->lvl_n.size();
-    const double* in = nullptr;  // level 0 reads the weight column of the view
+    const double* in = lin;  // nullptr: level 0 reads the weight column of the view
     for (int l = 0; l < L; ++l)
     {
         const int64_t nl = h->lvl_n[l];
@@ -509,7 +531,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
                     h->grid,  h->clr,    h->maps, h->maps2,    h->luts,         h->scan_dev,
                     h->inj_normals, h->inj_uniforms, h->idx, h->perm, h->slots, h->src,   h->keys, h->keys2,
                     h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
-                    h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp};
+                    h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->wlin, h->wmax};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (size_t l = 0; l < h->lvl_s.size(); ++l)
@@ -570,6 +592,13 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
     TRY(dev_alloc(&h->stats, 3));
     TRY(dev_alloc(&h->luts, 512));
     TRY(dev_alloc(&h->partials, 4 * (size_t)cdiv(n, 256)));
+    if (h->prm.weight_domain != SLAM_WEIGHT_LINEAR && h->prm.weight_domain != SLAM_WEIGHT_LOG)
+        rc = fail(SLAM_ERR_ARG, "weight_domain must be SLAM_WEIGHT_LINEAR or SLAM_WEIGHT_LOG");
+    if (h->prm.weight_domain == SLAM_WEIGHT_LOG)
+    {
+        TRY(dev_alloc(&h->wlin, (size_t)h->n_glob));
+        TRY(dev_alloc(&h->wmax, 2 * (size_t)cdiv(h->n_glob, 256) + 64));
+    }
     if (!rc && h->n_glob != n && (h->prm.sort != SLAM_SORT_NONE || h->prm.prefix_order != SLAM_PREFIX_BLOCKED))
         rc = fail(SLAM_ERR_ARG, "a shard (global_n > n_particles) needs SLAM_SORT_NONE and SLAM_PREFIX_BLOCKED");
     if (h->prm.noise == SLAM_NOISE_INJECTED)

@@ -35,7 +35,7 @@ class Filter:
     def __init__(self, n_particles, rows, cols, mode=capi.MODE_LOCALIZATION, device=0, seed=0x5EED0001,
                  noise=capi.NOISE_PHILOX, prefix_order=capi.PREFIX_BLOCKED, resampler=capi.RESAMPLE_MULTINOMIAL,
                  sort=capi.SORT_FULL, raycaster=capi.RAYCAST_FAST, global_first=0, global_n=0, stream=None,
-                 async_launch=False):
+                 async_launch=False, weight_domain=capi.WEIGHT_LINEAR):
         self.lib = capi.load_library()
         p = capi.Params()
         p.struct_size = ctypes.sizeof(capi.Params)
@@ -53,6 +53,7 @@ class Filter:
         p.global_n = global_n
         p.stream = stream
         p.async_launch = 1 if async_launch else 0
+        p.weight_domain = weight_domain
         self.params = p
         self.n = int(n_particles)
         self.global_n = int(global_n) if global_n else int(n_particles)

@@ -74,7 +74,7 @@ def measurement_model_beam(grid, px, py, theta, d2, stddev, max2, write=True, ma
 
 
 def update_weights(x, y, th, grids, angles, dists, stddev, max_dist, offset=(0, 0, 0), slam_mode=False, math=LIBM,
-                   n_threads=1, want_hits=False, fast=False):
+                   n_threads=1, want_hits=False, fast=False, log_domain=False):
     """The weighting half of MCL::update.  slam_mode: grids is (N, rows, cols), updated in place.
     Otherwise grids is the shared (rows, cols) map."""
     x, y, th = _f(x), _f(y), _f(th)
@@ -91,10 +91,19 @@ def update_weights(x, y, th, grids, angles, dists, stddev, max_dist, offset=(0, 
     st = (ctypes.c_long * 3)()
     rc = lib(fast).orc_update_weights(int(slam_mode), ctypes.c_long(N), _p(x), _p(y), _p(th), _p(grids), rows, cols, B,
                                       _p(angles), _p(dists), ctypes.c_double(stddev), ctypes.c_double(max_dist),
-                                      _p(offset), math, n_threads, _p(w), _p(hit_xy), _p(hit_cell), st)
+                                      _p(offset), math | (2 if log_domain else 0), n_threads, _p(w), _p(hit_xy),
+                                      _p(hit_cell), st)
     assert rc == 0
     stats = {"cells_read": st[0], "cells_written": st[1], "steps": st[2]}
     return (w, hit_xy, hit_cell, stats) if want_hits else (w, stats)
+
+
+def log_domain_weights(lw, math=LIBM):
+    """exp(lw - max lw): what the selection runs on in the log-domain mode."""
+    lw = _f(lw)
+    out = np.empty_like(lw)
+    lib().orc_log_domain_weights(ctypes.c_long(lw.size), _p(lw), math, _p(out))
+    return out
 
 
 def predict(x, y, th, odom, alphas, z, math=LIBM):

@@ -564,6 +564,130 @@ def test_sharded_slam_mode_matches_single_handle(sa, shards):
         assert np.array_equal(sf.b.f.map_of(p), m1[idx[p]])
 
 
+# ---- log-domain weights (opt-in extension) ----------------------------------------
+@pytest.mark.parametrize("raycaster,order", [("beam_lanes", "blocked"), ("particle_lanes", "blocked"), ("walk", "reference")])
+def test_log_domain_weights_and_selection(sa, raycaster, order):
+    """B = 720: the reference's exp(sum of logs) is 0 for almost every particle; the
+    log-domain mode keeps the sum and selects on exp(lw - max).  Both against the oracle, bit for bit."""
+    rng = np.random.default_rng(51)
+    N, B, seed = 3000, 720, 0x106
+    free = orc.load_map("floor_plan")
+    g = (free * 255).astype(np.uint8)
+    rows, cols = g.shape
+    true = [520.0, 280.0, 0.4]
+    ang, dist = orc.make_scan(free, true, OFFSET, B)
+    x, y, th = cloud(rng, N, true[0], true[1], sxy=0.2, sth=0.001, th0=true[2])   # tight: many particles keep some mass
+    po = sa.capi.PREFIX_BLOCKED if order == "blocked" else sa.capi.PREFIX_REFERENCE
+    oo = orc.ORDER_BLOCKED if order == "blocked" else orc.ORDER_REFERENCE
+    f = sa.Filter(N, rows, cols, seed=seed, raycaster=RAYCASTERS[raycaster], prefix_order=po, sort=sa.capi.SORT_NONE,
+                  weight_domain=sa.capi.WEIGHT_LOG)
+    lin = sa.Filter(N, rows, cols, seed=seed, raycaster=RAYCASTERS[raycaster], sort=sa.capi.SORT_NONE)
+    for q in (f, lin):
+        q.set_map(g)
+        q.set_poses(x, y, th)
+        q.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+    olw, _ = orc.update_weights(x, y, th, g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET, log_domain=True)
+    lw = f.weights()
+    assert_bits(lw, olw, "sum of log likelihoods")
+    assert np.all(np.isfinite(lw)) and lw.max() < 0
+    assert (lin.weights() == 0).mean() > 0.5                    # what the linear domain makes of this scan
+    f.resample()
+    wl = orc.log_domain_weights(olw, orc.DET)
+    assert wl.max() == 1.0
+    idx, P, _ = orc.resample(wl, orc.philox_uniforms(seed, 0, 0, N), oo)
+    assert_bits(f.prefix()[0], P, "running sum of exp(lw - max)")
+    assert np.array_equal(f.last_indices(), idx)
+    assert_bits(f.weights(), olw[idx], "weights after the gather stay in the log domain")
+    assert np.unique(idx).size > 1
+    f.close(), lin.close()
+
+
+def test_log_domain_slam_mode_and_sort(sa):
+    rng = np.random.default_rng(52)
+    N, B, rows, cols, zmax, seed = 64, 500, 160, 200, 90.0, 0x107
+    free = orc.load_map("map")
+    ang, dist = orc.make_scan(free, [400.0, 400.0, np.pi / 90], OFFSET, B, max_dist=zmax)
+    x, y, th = cloud(rng, N, cols / 2, rows / 2, sxy=3.0, sth=0.2, th0=np.pi / 2)
+    f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed, weight_domain=sa.capi.WEIGHT_LOG)
+    f.set_poses(x, y, th)
+    maps = np.full((N, rows, cols), 128, np.uint8)
+    for it in range(2):
+        f.update_weights(ang, dist, 5.0, zmax, OFFSET)
+        olw, _ = orc.update_weights(x, y, th, maps, ang, dist, 5.0, zmax, OFFSET, slam_mode=True, math=orc.DET, log_domain=True)
+        assert_bits(f.weights(), olw, f"pass {it}")
+    f.resample()
+    idx, _, _ = orc.resample(orc.log_domain_weights(olw, orc.DET), orc.philox_uniforms(seed, 0, 0, N), orc.ORDER_BLOCKED)
+    assert np.array_equal(f.last_indices(), idx)
+    perm = f.last_order()
+    sel = olw[idx]
+    assert np.array_equal(perm, orc.sort_order(sel, 0))        # (log-weight desc, slot asc): same order as the weights
+    assert_bits(f.weights(), sel[perm], "sorted log weights")
+    for p in range(0, N, 5):
+        assert np.array_equal(f.map_of(p), maps[idx[perm[p]]])
+    f.close()
+
+
+# ---- per-GPU shard sizes of BASELINE configs[2] (10M x 1080 over 8 GPUs) and [4] (100M x 720 over 8) ---
+@pytest.mark.parametrize("size,N,B,zmax,uniform", [(8192, 1_250_000, 1080, 500.0, False), (16384, 12_500_000, 720, 4000.0, True)])
+def test_full_shard_sizes_of_configs_3_and_5(sa, size, N, B, zmax, uniform):
+    """One GPU's share of the two 8-GPU configurations, through properties the size does not change:
+    a random subset of the particles recomputed by the cell-by-cell kernel gives the same bits, the
+    pass is idempotent, the running sum ends at the sum and the selection stays in range.  Log-domain
+    weights: at these beam counts the linear weights are all zero."""
+    import time
+
+    from slam_amd import synth
+
+    g = synth.make_grid(size)
+    free01 = (g >= 128).astype(np.uint8)
+    rng = np.random.default_rng(size + 1)
+    free_cells = np.argwhere(g[size // 4:size // 4 + 64, size // 4:size // 4 + 2000] >= 128)
+    ci, cj = free_cells[len(free_cells) // 2]
+    true = [float(cj + size // 4) + 0.5, float(size - 1 - (ci + size // 4)) + 0.5, 0.7]
+    lib = sa.capi.load_library()
+    sensor = orc.sensor_position(true, OFFSET, orc.DET)
+    hits = np.empty((B, 2))
+    sa.capi.check(lib.slam_fake_lidar_scan(0, sa.capi.ptr(free01), size, size, sa.capi.ptr(np.ascontiguousarray(sensor[None])), 1,
+                                           0.0, 2 * np.pi, zmax, B, sa.capi.ptr(hits)))
+    ang, dist = orc.hits_to_scan(hits, sensor, 0.0, 2 * np.pi, zmax)
+    seed = 0x5EED1000 + size
+    f = sa.Filter(N, size, size, seed=seed, sort=sa.capi.SORT_NONE, weight_domain=sa.capi.WEIGHT_LOG)
+    f.set_map(g)
+    if uniform:
+        f.seed_uniform_free()
+    else:
+        f.seed_gaussian(true, [25.0, 25.0, 0.2])
+    f.predict(ODOM, ALPHAS)
+    t0 = time.perf_counter()
+    f.update_weights(ang, dist, 0.5, zmax, OFFSET)
+    dt = time.perf_counter() - t0
+    print(f"\n{N} x {B} on {size}^2: weighting pass {dt * 1e3:.1f} ms = {N * B / dt / 1e9:.1f} G particle-beams/s")
+    x, y, th = f.poses()
+    lw = f.weights()
+    assert np.all(np.isfinite(lw)) and lw.max() < 0
+    sub = np.sort(rng.choice(N, 4096, replace=False))
+    walk = sa.Filter(sub.size, size, size, raycaster=sa.capi.RAYCAST_WALK, sort=sa.capi.SORT_NONE,
+                     weight_domain=sa.capi.WEIGHT_LOG)
+    walk.set_map(g)
+    walk.set_poses(x[sub], y[sub], th[sub])
+    walk.update_weights(ang, dist, 0.5, zmax, OFFSET)
+    assert_bits(lw[sub], walk.weights(), "subset recomputed cell by cell")
+    walk.close()
+    osub = sub[:24]
+    olw, _ = orc.update_weights(x[osub], y[osub], th[osub], g, ang, dist, 0.5, zmax, OFFSET, math=orc.DET, log_domain=True)
+    assert_bits(lw[osub], olw, "subset vs oracle")
+    f.update_weights(ang, dist, 0.5, zmax, OFFSET)
+    assert_bits(f.weights(), lw, "idempotence")
+    f.resample()
+    P, total = f.prefix()
+    # (the blocked order is monotone up to the rounding at chunk seams)
+    assert np.all(np.diff(P) >= -1e-12 * total) and P[-1] == total and 1.0 <= total <= N
+    idx = f.last_indices()
+    assert idx.min() >= 0 and idx.max() < N
+    assert_bits(f.weights(), lw[idx], "gathered weights")
+    f.close()
+
+
 # ---- BASELINE configs[2] and [4] at reduced particle counts: synthetic grids, long ranges, seeding ----
 def test_seeding_matches_host_replay(sa):
     from slam_amd import synth
