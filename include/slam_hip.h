@@ -110,6 +110,11 @@ int slam_mcl_set_noise(slam_mcl* h, const double* unit_normals, const double* ca
  * for every particle.  odom = {rotation_1, translation, rotation_2}. */
 int slam_mcl_predict(slam_mcl* h, const double odom[3], const double alphas[4]);
 
+/* sample_motion_model_velocity (slam/motion.cpp:34-56) for every particle: vel = {v, w}.  The
+ * reference has no filter-level caller for it (MCL::predict takes Odometry); same noise seam and
+ * streams as slam_mcl_predict, draws in the order v, w, gamma. */
+int slam_mcl_predict_velocity(slam_mcl* h, const double vel[2], double dt, const double alphas[6]);
+
 /* slam::MCL::update (slam/mcl.cpp:102-145): weights from raycast_mapping + measurement_model_beam
  * (slam/raycast.cpp:143-242, slam/mcl.cpp:49-78), then resample_particles (slam/mcl.cpp:157-239).
  * scan is (angle, dist) per beam as built by the callers (benchmark/mcl.cpp:37-56). */

@@ -284,6 +284,26 @@ void sample_motion_model_odometry(const double odom[3], const double alphas[4], 
     th = angle;
 }
 
+// slam/motion.cpp:34-56 sample_motion_model_velocity with the same noise seam: z[0..2] are the unit
+// normals behind the three draws (v, w, gamma), in the order the reference draws them.
+template <class M>
+void sample_motion_model_velocity(const double vel[2], double dt, const double alphas[6], const double z[3], double& x,
+                                  double& y, double& th)
+{
+    constexpr double EPSILON = 1e-6;
+    const double v0 = vel[0], w0 = vel[1];
+    const double v = v0 + z[0] * std::sqrt(alphas[0] * (v0 * v0) + alphas[1] * (w0 * w0));
+    const double w = w0 + z[1] * std::sqrt(alphas[2] * (w0 * w0) + alphas[3] * (v0 * v0));
+    const double gamma = z[2] * std::sqrt(alphas[4] * (v0 * v0) + alphas[5] * (w0 * w0));
+    const double nx = x - v / (w == 0 ? 1 : w) * (M::sin(th) + M::sin(th + (w + EPSILON) * dt));
+    const double ny = y + v / (w == 0 ? 1 : w) * (M::cos(th) - M::cos(th + (w + EPSILON) * dt));
+    double angle = M::fmod2pi(th + w * dt + gamma * dt);
+    if (angle > M_PI) angle -= 2 * M_PI;
+    x = nx;
+    y = ny;
+    th = angle;
+}
+
 // Canonical blocked prefix order (radix-64 hierarchy of Hillis-Steele scans); the HIP kernels
 // implement exactly this order, independent of the number of GPUs.
 void hs_scan_chunks(const double* a, long n, double* s)
@@ -536,6 +556,42 @@ ORC_API void orc_predict(long N, double* x, double* y, double* th, const double*
             sample_motion_model_odometry<DetMath>(odom3, alphas4, z + 3 * p, x[p], y[p], th[p]);
         else
             sample_motion_model_odometry<LibmMath>(odom3, alphas4, z + 3 * p, x[p], y[p], th[p]);
+    }
+}
+
+// slam/motion.cpp:34-56 for N poses with injected unit normals z[3*N].
+ORC_API void orc_predict_velocity(long N, double* x, double* y, double* th, const double* vel2, double dt,
+                                  const double* alphas6, const double* z, int math)
+{
+    for (long p = 0; p < N; ++p)
+    {
+        if (math)
+            sample_motion_model_velocity<DetMath>(vel2, dt, alphas6, z + 3 * p, x[p], y[p], th[p]);
+        else
+            sample_motion_model_velocity<LibmMath>(vel2, dt, alphas6, z + 3 * p, x[p], y[p], th[p]);
+    }
+}
+
+// slam/util.cpp:36-43 sample_triangular_distribution: one clock re-seed, then TWO draws of
+// uniform_real_distribution(-stddev, stddev) from the same engine; the first is scaled by sqrt(6)/2.
+ORC_API void orc_reference_triangular(long n, long tick0, long tick_stride, double stddev, double* out)
+{
+    for (long k = 0; k < n; ++k)
+    {
+        std::default_random_engine generator;
+        generator.seed(static_cast<unsigned long>(tick0 + k * tick_stride));
+        std::uniform_real_distribution<double> distribution(-stddev, stddev);
+        out[k] = std::sqrt(6) / 2 * (distribution(generator)) + distribution(generator);
+    }
+}
+
+// slam/util.cpp:20-24 pdf_triangular_distribution.
+ORC_API void orc_pdf_triangular(long n, double stddev, const double* x, double* out)
+{
+    for (long k = 0; k < n; ++k)
+    {
+        const double variance = stddev * stddev;
+        out[k] = std::max(0.0, 1 / std::sqrt(6 * variance) - std::fabs(x[k]) / 6 / variance);
     }
 }
 

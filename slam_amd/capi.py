@@ -79,6 +79,7 @@ SYMBOLS = {
     "slam_mcl_set_noise": (ctypes.c_int, [_P, _P, _P]),
     "slam_mcl_predict": (ctypes.c_int, [_P, _P, _P]),
     "slam_mcl_update": (ctypes.c_int, [_P, _P, _P, _I32, _D, _D, _P]),
+    "slam_mcl_predict_velocity": (ctypes.c_int, [_P, _P, _D, _P]),
     "slam_mcl_update_weights": (ctypes.c_int, [_P, _P, _P, _I32, _D, _D, _P]),
     "slam_mcl_resample": (ctypes.c_int, [_P]),
     "slam_mcl_shard_resample": (ctypes.c_int, [_P, _P, _I32]),

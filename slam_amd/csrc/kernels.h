@@ -63,6 +63,49 @@ __global__ void __launch_bounds__(256) k_predict(PredictArgs a)
     a.th[p] = angle;
 }
 
+// slam/motion.cpp:34-56 sample_motion_model_velocity for every particle (no caller in the reference;
+// same noise seam and streams as k_predict: draws v, w, gamma in that order).
+struct PredictVelArgs
+{
+    int64_t n;
+    double *x, *y, *th;
+    double v, w, dt;
+    double sv, sw, sg;  // the three sigmas of slam/motion.cpp:40-45
+    uint64_t seed, step, global_first;
+    const double* injected;
+};
+
+__global__ void __launch_bounds__(256) k_predict_velocity(PredictVelArgs a)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    double z[3];
+    if (a.injected)
+    {
+        z[0] = a.injected[3 * p];
+        z[1] = a.injected[3 * p + 1];
+        z[2] = a.injected[3 * p + 2];
+    }
+    else
+        slam_motion_normals(a.seed, a.step, a.global_first + (uint64_t)p, z);
+    const double v = a.v + z[0] * a.sv;
+    const double w = a.w + z[1] * a.sw;
+    const double gamma = z[2] * a.sg;
+    const double th = a.th[p];
+    double s0, c0, s1, c1;
+    dm_sincos(th, &s0, &c0);
+    dm_sincos(th + (w + 1e-6) * a.dt, &s1, &c1);
+    const double q = v / (w == 0 ? 1 : w);
+    const double nx = a.x[p] - q * (s0 + s1);
+    const double ny = a.y[p] + q * (c0 - c1);
+    const double twopi = dm_from_bits(0x401921FB54442D18ull);
+    double angle = dm_fmod_pos(th + w * a.dt + gamma * a.dt, twopi);
+    if (angle > dm_from_bits(0x400921FB54442D18ull)) angle -= twopi;
+    a.x[p] = nx;
+    a.y[p] = ny;
+    a.th[p] = angle;
+}
+
 // ------------------------------------------------------------------------------------------------
 struct WeightArgs
 {

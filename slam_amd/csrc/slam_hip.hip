@@ -829,6 +829,44 @@ SLAM_API int slam_mcl_predict(slam_mcl* h, const double odom[3], const double al
     return maybe_finish(h);
 }
 
+SLAM_API int slam_mcl_predict_velocity(slam_mcl* h, const double vel[2], double dt, const double alphas[6])
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!vel || !alphas) return fail(SLAM_ERR_ARG, "predict_velocity: null");
+    if (!std::isfinite(vel[0]) || !std::isfinite(vel[1]) || !std::isfinite(dt))
+        return fail(SLAM_ERR_ARG, "predict_velocity: non-finite velocity or dt");
+    for (int k = 0; k < 6; ++k)
+        if (!std::isfinite(alphas[k]) || alphas[k] < 0)
+            return fail(SLAM_ERR_ARG, "predict_velocity: alphas must be finite and >= 0");
+    const bool injected = h->prm.noise == SLAM_NOISE_INJECTED;
+    if (injected && !h->have_normals) return fail(SLAM_ERR_STATE, "injected noise: no normals set for this predict");
+    slamk::PredictVelArgs a;
+    a.n = h->n;
+    a.x = h->x;
+    a.y = h->y;
+    a.th = h->th;
+    a.v = vel[0];
+    a.w = vel[1];
+    a.dt = dt;
+    // slam/motion.cpp:40-45 (std::pow(v, 2) is v*v)
+    a.sv = std::sqrt(alphas[0] * (a.v * a.v) + alphas[1] * (a.w * a.w));
+    a.sw = std::sqrt(alphas[2] * (a.w * a.w) + alphas[3] * (a.v * a.v));
+    a.sg = std::sqrt(alphas[4] * (a.v * a.v) + alphas[5] * (a.w * a.w));
+    a.seed = h->prm.seed;
+    a.step = h->predict_step;
+    a.global_first = (uint64_t)h->prm.global_first;
+    a.injected = injected ? h->inj_normals : nullptr;
+    {
+        slam_mcl::Span span(h, G_PREDICT);
+        hipLaunchKernelGGL(slamk::k_predict_velocity, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    h->predict_step++;
+    h->have_normals = false;
+    return maybe_finish(h);
+}
+
 SLAM_API int slam_mcl_update_weights(slam_mcl* h, const double* angles, const double* dists, int32_t n_beams,
                                      double stddev, double max_dist, const double scanner_offset[3])
 {

@@ -19,6 +19,12 @@ struct Odometry
     double rotation_2;
 };
 
+struct Velocity
+{
+    double v;
+    double w;
+};
+
 struct Particle
 {
     Pose pose;

@@ -1,5 +1,6 @@
 // slam_host.cpp — C++ shim: the reference's public classes over the C ABI of libslam_hip.so.
 // Errors from the library are fatal here (the reference's interface returns void everywhere).
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -111,20 +112,64 @@ double normalize_angle(double angle)
     return angle;
 }
 
+// slam/util.cpp:9-43, host scalars
+double pdf_normal_distribution(double stddev, double x)
+{
+    return (1.0 / (stddev * std::sqrt(2 * M_PI))) * std::exp(-0.5 * std::pow(x / stddev, 2));
+}
+
+double pdf_normal_distribution_clamp(double stddev, double x, double multiple_stddev)
+{
+    if (std::fabs(x) > multiple_stddev * stddev) return 0;
+    return pdf_normal_distribution(stddev, x);
+}
+
+double pdf_triangular_distribution(double stddev, double x)
+{
+    const double variance = std::pow(stddev, 2);
+    return std::max(0.0, 1 / std::sqrt(6 * variance) - std::fabs(x) / 6 / variance);
+}
+
+double sample_normal_distribution(double stddev)
+{
+    static thread_local std::default_random_engine generator;
+    generator.seed(std::chrono::system_clock::now().time_since_epoch().count());
+    std::normal_distribution<double> distribution(0, stddev);
+    return distribution(generator);
+}
+
+double sample_triangular_distribution(double stddev)
+{
+    static thread_local std::default_random_engine generator;
+    generator.seed(std::chrono::system_clock::now().time_since_epoch().count());
+    std::uniform_real_distribution<double> distribution(-stddev, stddev);
+    const double first = distribution(generator);
+    return std::sqrt(6) / 2 * first + distribution(generator);
+}
+
 Pose sample_motion_model_odometry(const Odometry& odom, const Pose& pose, std::array<double, 4> alphas)
 {
     // slam/motion.cpp:9-32 for ONE pose (the ground-truth robot of the callers), noise as in slam/util.cpp:27-34
-    auto sample = [](double stddev) {
-        static thread_local std::default_random_engine generator;
-        generator.seed(std::chrono::system_clock::now().time_since_epoch().count());
-        std::normal_distribution<double> distribution(0, stddev);
-        return distribution(generator);
-    };
+    auto sample = sample_normal_distribution;
     const double r1 = odom.rotation_1 - sample(std::sqrt(alphas[0] * std::pow(odom.rotation_1, 2) + alphas[1] * std::pow(odom.translation, 2)));
     const double t = odom.translation - sample(std::sqrt(alphas[2] * std::pow(odom.translation, 2) +
                                                          alphas[3] * (std::pow(odom.rotation_1, 2) + std::pow(odom.rotation_2, 2))));
     const double r2 = odom.rotation_2 - sample(std::sqrt(alphas[0] * std::pow(odom.rotation_2, 2) + alphas[1] * std::pow(odom.translation, 2)));
     return {pose.x + t * std::cos(pose.theta + r1), pose.y + t * std::sin(pose.theta + r1), normalize_angle(pose.theta + r1 + r2)};
+}
+
+Pose sample_motion_model_velocity(const Velocity& vel, const Pose& pose, double dt, std::array<double, 6> alphas)
+{
+    // slam/motion.cpp:34-56 for ONE pose; the per-particle form is slam_mcl_predict_velocity
+    constexpr double EPSILON = 1e-6;
+    auto sample = sample_normal_distribution;
+    const double v = vel.v + sample(std::sqrt(alphas[0] * std::pow(vel.v, 2) + alphas[1] * std::pow(vel.w, 2)));
+    const double w = vel.w + sample(std::sqrt(alphas[2] * std::pow(vel.w, 2) + alphas[3] * std::pow(vel.v, 2)));
+    const double gamma = sample(std::sqrt(alphas[4] * std::pow(vel.v, 2) + alphas[5] * std::pow(vel.w, 2)));
+    const double q = v / (w == 0 ? 1 : w);
+    return {pose.x - q * (std::sin(pose.theta) + std::sin(pose.theta + (w + EPSILON) * dt)),
+            pose.y + q * (std::cos(pose.theta) - std::cos(pose.theta + (w + EPSILON) * dt)),
+            normalize_angle(pose.theta + w * dt + gamma * dt)};
 }
 
 Pose average_pose(const std::vector<Particle>& particles)

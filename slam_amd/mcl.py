@@ -109,6 +109,13 @@ class Filter:
         o, a = f64(odom), f64(alphas)
         check(self.lib.slam_mcl_predict(self._h, ptr(o), ptr(a)), self.lib)
 
+    def predict_velocity(self, vel, dt, alphas):
+        """slam/motion.cpp:34-56 for every particle; vel = (v, w), six alphas."""
+        v = np.ascontiguousarray(vel, dtype=np.float64)
+        a = np.ascontiguousarray(alphas, dtype=np.float64)
+        assert v.size == 2 and a.size == 6
+        check(self.lib.slam_mcl_predict_velocity(self._h, ptr(v), float(dt), ptr(a)), self.lib)
+
     def _scan(self, angles, dists, offset):
         a, d, o = f64(angles), f64(dists), f64(offset)
         self._last_B = a.size

@@ -114,6 +114,28 @@ def predict(x, y, th, odom, alphas, z, math=LIBM):
     return x, y, th
 
 
+def predict_velocity(x, y, th, vel, dt, alphas, z, math=LIBM):
+    x, y, th = _f(x).copy(), _f(y).copy(), _f(th).copy()
+    vel, alphas, z = _f(vel), _f(alphas), _f(z)
+    assert z.size == 3 * x.size and vel.size == 2 and alphas.size == 6
+    lib().orc_predict_velocity(ctypes.c_long(x.size), _p(x), _p(y), _p(th), _p(vel), ctypes.c_double(dt), _p(alphas), _p(z), math)
+    return x, y, th
+
+
+def reference_triangular(n, tick0=1, tick_stride=1, stddev=1.0):
+    out = np.empty(n)
+    lib().orc_reference_triangular(ctypes.c_long(n), ctypes.c_long(tick0), ctypes.c_long(tick_stride),
+                                   ctypes.c_double(stddev), _p(out))
+    return out
+
+
+def pdf_triangular(stddev, x):
+    x = _f(x)
+    out = np.empty_like(x)
+    lib().orc_pdf_triangular(ctypes.c_long(x.size), ctypes.c_double(stddev), _p(x), _p(out))
+    return out
+
+
 def reference_normals(n, tick0=1, tick_stride=1, stddev=1.0):
     out = np.empty(n)
     lib().orc_reference_normals(ctypes.c_long(n), ctypes.c_long(tick0), ctypes.c_long(tick_stride),

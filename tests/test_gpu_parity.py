@@ -91,6 +91,37 @@ def test_predict_philox_matches_host_stream_and_shards(sa):
 
 
 # ---- K2a raycast + likelihood, localization mode -------------------------------------------------
+def test_predict_velocity_model(sa):
+    """slam/motion.cpp:34-56 per particle: injected normals and the Philox stream, both against the oracle."""
+    rng = np.random.default_rng(12)
+    N, seed = 5000, 0x7E1
+    x, y, th = rng.uniform(0, 500, N), rng.uniform(0, 500, N), rng.uniform(-2 * np.pi, np.pi, N)
+    vel, dt, al = [1.7, 0.3], 0.25, [1e-2, 2e-2, 3e-2, 4e-2, 5e-3, 6e-3]
+    z = rng.standard_normal(3 * N)
+    f = sa.Filter(N, 600, 600, noise=sa.capi.NOISE_INJECTED)
+    f.set_poses(x, y, th)
+    f.set_noise(unit_normals=z)
+    f.predict_velocity(vel, dt, al)
+    ex = orc.predict_velocity(x, y, th, vel, dt, al, z, math=orc.DET)
+    for q in range(3):
+        assert_bits(f.poses()[q], ex[q], "injected normals")
+    lm = orc.predict_velocity(x, y, th, vel, dt, al, z)
+    for q in range(3):
+        assert np.allclose(f.poses()[q], lm[q], rtol=REL_TOL, atol=1e-9)
+    f.close()
+    f = sa.Filter(N, 600, 600, seed=seed)
+    f.set_poses(x, y, th)
+    f.predict_velocity([2.0, 0.0], 0.5, [0.0] * 6)          # w == 0: divides by 1, no noise
+    st = orc.predict_velocity(x, y, th, [2.0, 0.0], 0.5, [0.0] * 6, np.zeros(3 * N), math=orc.DET)
+    f.predict_velocity(vel, dt, al)                          # second predict: Philox step 1
+    ex = orc.predict_velocity(*st, vel, dt, al, orc.philox_normals(seed, 1, 0, N), math=orc.DET)
+    for q in range(3):
+        assert_bits(f.poses()[q], ex[q], "philox stream")
+    with pytest.raises(RuntimeError):
+        f.predict_velocity([np.nan, 0.0], 0.1, [0.0] * 6)
+    f.close()
+
+
 RAYCASTERS = {"fast": 0, "walk": 1, "beam_lanes": 2, "particle_lanes": 3}
 
 

@@ -134,6 +134,55 @@ def test_reference_noise_source_is_libstdcpp():
     assert orc.reference_uniforms(1, tick=1)[0] == ((g1 - 1) + (g2 - 1) * float(m - 1)) / (float(m - 1) ** 2)
 
 
+def test_triangular_sampler_is_two_draws_of_one_engine():
+    """slam/util.cpp:36-43: ONE re-seed, two uniform(-s, s) draws from the same minstd_rand0, the
+    first scaled by sqrt(6)/2.  Checked against an integer model of libstdc++'s generate_canonical."""
+    m = 2147483647
+
+    def canonical(x):  # two engine outputs per double (range 2^31 - 2 < 2^53)
+        x1 = (16807 * x) % m
+        x2 = (16807 * x1) % m
+        return ((x1 - 1) + (x2 - 1) * float(m - 1)) / (float(m - 1) ** 2), x2
+
+    for tick, sd in [(1, 1.0), (12345, 2.5), (987654321, 0.125)]:
+        c1, st = canonical(tick % m or 1)
+        c2, _ = canonical(st)
+        expect = np.sqrt(6.0) / 2 * (c1 * (sd - -sd) + -sd) + (c2 * (sd - -sd) + -sd)
+        assert orc.reference_triangular(1, tick, 0, sd)[0] == expect
+    t = orc.reference_triangular(200000, 99, 1, 1.0)
+    assert abs(t.mean()) < 0.01 and np.abs(t).max() <= np.sqrt(6) / 2 + 1
+    x = np.array([0.0, 0.5, -0.5, 3.0, -7.0])
+    assert np.array_equal(orc.pdf_triangular(1.5, x), np.maximum(0.0, 1 / np.sqrt(6 * 1.5 ** 2) - np.abs(x) / 6 / 1.5 ** 2))
+
+
+def test_velocity_motion_model_matches_formula():
+    """slam/motion.cpp:34-56 as written (the + between the two sines included)."""
+    import math
+
+    N = 300
+    x, y, th = rng.uniform(0, 100, N), rng.uniform(0, 100, N), rng.uniform(-2 * np.pi, np.pi, N)
+    z = orc.reference_normals(3 * N, 5, 1)
+    vel, dt, al = [1.7, 0.3], 0.25, [1e-2, 2e-2, 3e-2, 4e-2, 5e-3, 6e-3]
+    nx, ny, nth = orc.predict_velocity(x, y, th, vel, dt, al, z)
+    vv, ww = vel[0] * vel[0], vel[1] * vel[1]     # std::pow(v, 2)
+    sv = math.sqrt(al[0] * vv + al[1] * ww)
+    sw = math.sqrt(al[2] * ww + al[3] * vv)
+    sg = math.sqrt(al[4] * vv + al[5] * ww)
+    for p in range(N):
+        v, w, g = vel[0] + z[3 * p] * sv, vel[1] + z[3 * p + 1] * sw, z[3 * p + 2] * sg
+        q = v / (1 if w == 0 else w)
+        assert nx[p] == x[p] - q * (math.sin(th[p]) + math.sin(th[p] + (w + 1e-6) * dt))
+        assert ny[p] == y[p] + q * (math.cos(th[p]) - math.cos(th[p] + (w + 1e-6) * dt))
+        a = math.fmod(th[p] + w * dt + g * dt, 2 * math.pi)
+        assert nth[p] == (a - 2 * math.pi if a > math.pi else a)
+    # w == 0 divides by 1 (slam/motion.cpp:48,51); zero alphas are deterministic
+    ox, oy, oth = orc.predict_velocity([1.0], [2.0], [0.5], [2.0, 0.0], 0.5, [0] * 6, [9.0, 9.0, 9.0])
+    assert ox[0] == 1.0 - 2.0 * (math.sin(0.5) + math.sin(0.5 + 1e-6 * 0.5)) and oth[0] == 0.5
+    # deterministic math agrees with libm to the stated tolerance
+    dx, dy, dth = orc.predict_velocity(x, y, th, vel, dt, al, z, math=orc.DET)
+    assert np.allclose(dx, nx, rtol=1e-12) and np.allclose(dy, ny, rtol=1e-12) and np.allclose(dth, nth, rtol=1e-12, atol=1e-15)
+
+
 def test_predict_matches_formula_and_normalizes_angle():
     N = 1000
     x, y, th = rng.uniform(0, 100, N), rng.uniform(0, 100, N), rng.uniform(-2 * np.pi, np.pi, N)
