@@ -232,23 +232,30 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
 }
 
 // Pose-coherent order for k_rays_pl.  The weight of a particle does not depend on which lane
-// computes it, so the particles are dealt to wavefronts by a key of (heading bucket, 2-cell tile):
+// computes it, so the particles are dealt to wavefronts by a key of (heading bucket, 4-cell tile):
 // the 64 rays a wavefront walks together then start from the same few cells with headings within
-// 1/256 turn, take nearly the same number of lookups and touch the same cache lines.  Keys wrap
-// (12 bits per axis): far-apart particles that alias only cost coherence, never correctness.
+// 1/1024 turn, take nearly the same number of lookups and touch the same cache lines.  Keys wrap
+// (11 bits per axis): far-apart particles that alias only cost coherence, never correctness.
 __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, const double* y, const double* th,
                                                     int mode, uint32_t* keys, int32_t* ident)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const unsigned tx = ((unsigned)slam_f2i(x[p]) >> 1) & 0xfffu;
-    const unsigned ty = ((unsigned)slam_f2i(y[p]) >> 1) & 0xfffu;
-    // 1/(2 pi) to float precision is plenty for a bucket index
-    const unsigned tb = (unsigned)slam_f2i(th[p] * 40.74366543152521 + 1024.0) & 0xffu;
+    // mode = kind | (tile_shift + 1) << 4 | heading_bits << 8 (0 fields: 4-cell tiles, 10 heading bits:
+    // best for a converged cloud, 4 % over 2-cell tiles / 8 bits; a wide cloud prefers coarser headings)
+    const int kind = mode & 15;
+    const int tshift = ((mode >> 4) & 15) ? ((mode >> 4) & 15) - 1 : 2;
+    const int tbits = (mode >> 8) ? (mode >> 8) : 10;
+    const int nb = (32 - tbits) >> 1;
+    const unsigned tmask = (1u << nb) - 1u;
+    const unsigned tx = ((unsigned)slam_f2i(x[p]) >> tshift) & tmask;
+    const unsigned ty = ((unsigned)slam_f2i(y[p]) >> tshift) & tmask;
+    // heading in turns; 1/(2 pi) to double precision is plenty for a bucket index
+    const unsigned tb = (unsigned)slam_f2i((th[p] * 0.15915494309189535 + 4.0) * (double)(1u << tbits)) & ((1u << tbits) - 1u);
     unsigned k;
-    if (mode == 2)
-        k = (ty << 20) | (tx << 8) | tb;
-    else if (mode == 3)
+    if (kind == 2)
+        k = (ty << (nb + tbits)) | (tx << tbits) | tb;
+    else if (kind == 3)
     {  // Morton order of the tiles below the heading bucket
         unsigned a = tx, b = ty;
         a = (a | (a << 8)) & 0x00ff00ffu;
@@ -259,10 +266,10 @@ __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, 
         b = (b | (b << 4)) & 0x0f0f0f0fu;
         b = (b | (b << 2)) & 0x33333333u;
         b = (b | (b << 1)) & 0x55555555u;
-        k = (tb << 24) | (a | (b << 1));
+        k = (tb << (2 * nb)) | (a | (b << 1));
     }
     else
-        k = (tb << 24) | (ty << 12) | tx;
+        k = (tb << (2 * nb)) | (ty << nb) | tx;
     keys[p] = k;
     ident[p] = (int32_t)p;
 }
