@@ -196,7 +196,8 @@ template <int MIN_WAVES>
 __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (wave-uniform, and told so: beam index, scan entries and loop control then live in scalar registers)
+    const int64_t item = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // segment-major: the four wavefronts of a workgroup walk the same beams for neighbouring
     // (pose-sorted) particle blocks, i.e. the same map cells at about the same time
     const int seg = (int)(item / a.npblocks);
@@ -210,6 +211,9 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     dm_sincos(pth + a.stheta, &s0, &c0);
     const double sx = px + c0 * a.sd;
     const double sy = py + s0 * a.sd;
+    int i0, j0;
+    unsigned e0;
+    slam_ray_origin(a.grid, a.cols + 4, a.rows, a.cols, sx, sy, &i0, &j0, &e0, nullptr);
     double* slab = a.lw + (size_t)pb * (size_t)a.B * 64 + lane;
     const int b0 = seg * a.seg_beams;
     const int b1 = (b0 + a.seg_beams) < a.B ? (b0 + a.seg_beams) : a.B;
@@ -219,7 +223,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
         double s, c;
         dm_sincos(theta, &s, &c);
         slam_ray_result r;
-        ray_fast_L(a.grid, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr);
+        ray_fast_L0(a.grid, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, i0, j0, e0, &r, nullptr);
         slab[(size_t)b * 64] = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
         if (a.hit_xy)
         {

@@ -238,8 +238,25 @@ DM_HD void slam_advance(slam_axis* X, slam_axis* Y, double dx, double dy, int m)
 // k_safe = max(0, floor(zmax) - 1): for samples k <= k_safe the distance test of
 // slam/raycast.cpp:216 cannot fire (k^2 <= zmax^2 - 2 zmax + 1).
 //
-DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
-                      double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
+// The start cell of a ray and its clearance (0 when the origin is outside the grid): the same for
+// every beam of a particle, so the kernels look it up once per particle.
+DM_HD void slam_ray_origin(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, int* i0, int* j0,
+                           unsigned* e0, unsigned* reads)
+{
+    const int i = slam_f2i(((double)rows - sy) - 1.0), j = slam_f2i(sx);
+    unsigned e = 0;
+    if (slam_in_bounds(rows, cols, i, j))
+    {
+        e = Ep[(unsigned)(slam_mul24(i, pitch) + j + 2 * pitch + 2)];
+        if (reads) ++*reads;
+    }
+    *i0 = i;
+    *j0 = j;
+    *e0 = e;
+}
+
+DM_HD void ray_fast_L0(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
+                       double zmax2, int k_safe, int i0, int j0, unsigned e0, slam_ray_result* res, unsigned* reads)
 {
     res->hx = -1.0;
     res->hy = -1.0;
@@ -250,15 +267,10 @@ DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double s
     // anything farther out starts (and stays) outside every supported grid: literal loop only.
     int left = (dm_fabs(sx) < 1048576.0 && dm_fabs(sy) < 1048576.0) ? k_safe : 0;
     double x = sx, y = sy;
-    int i = slam_f2i((rows_d - y) - 1.0), j = slam_f2i(x);
     // sample 0 (the start cell) is never tested (slam/raycast.cpp:153-157); its clearance still
     // tells how far the first jump may go.
-    unsigned e = 0;
-    if (slam_in_bounds(rows, cols, i, j))
-    {
-        e = Ep[(unsigned)(slam_mul24(i, pitch) + j + org)];
-        if (reads) ++*reads;
-    }
+    int i = i0, j = j0;
+    unsigned e = e0;
     if (e == 0 && left > 0)
     {
         // start cell occupied or outside the grid: samples still inside it are skipped by the
@@ -390,6 +402,15 @@ DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double s
         pi = i;
         pj = j;
     }
+}
+
+DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
+                      double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
+{
+    int i0, j0;
+    unsigned e0;
+    slam_ray_origin(Ep, pitch, rows, cols, sx, sy, &i0, &j0, &e0, reads);
+    ray_fast_L0(Ep, pitch, rows, cols, sx, sy, dx, dy, zmax2, k_safe, i0, j0, e0, res, reads);
 }
 
 // ------------------------------------------------------------------------------------------------

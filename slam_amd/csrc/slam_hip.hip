@@ -358,7 +358,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             if (seg_env > 0) a.seg_beams = seg_env < B ? seg_env : B;
             a.nseg = (int)cdiv(B, a.seg_beams);
             const dim3 grid((unsigned)cdiv(a.npblocks * a.nseg, 4));
-            static const int pl_waves = getenv("SLAM_PL_WAVES") ? atoi(getenv("SLAM_PL_WAVES")) : 6;
+            static const int pl_waves = getenv("SLAM_PL_WAVES") ? atoi(getenv("SLAM_PL_WAVES")) : 5;
             if (pl_waves >= 8)
                 hipLaunchKernelGGL(slamk::k_rays_pl<8>, grid, dim3(256), 0, h->stream, a);
             else if (pl_waves >= 6)

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-# kind 3; tile shift field = shift+1; heading bits
-for M in 3 $((3+(1<<4)+(8<<8))) $((3+(2<<4)+(10<<8))) $((3+(3<<4)+(10<<8))) $((3+(2<<4)+(12<<8))) $((3+(3<<4)+(12<<8))) $((3+(4<<4)+(12<<8))) $((3+(2<<4)+(6<<8))) $((3+(3<<4)+(14<<8))); do echo "ORDER=$M"; SLAM_PL_ORDER=$M timeout -k 10 300 python -u tools/kbench.py 2>&1 | grep -E "particle_lanes|rror" | tr '\n' ' ' | sed 's/particle_lanes//g; s/G pb\/s//g; s/ms  ->  *[0-9.]*//g'; echo; done
+timeout -k 10 600 python -u -m pytest tests -m gpu --timeout 300 --timeout-method thread -q -x 2>&1 | tail -2
+for W in 6 5 4; do echo "WAVES=$W"; SLAM_PL_WAVES=$W timeout -k 10 300 python -u tools/kbench.py 2>&1 | grep -E "particle_lanes|rror" | tr '\n' ' ' | sed 's/particle_lanes//g; s/G pb\/s//g; s/ms  ->  *[0-9.]*//g'; echo; done
