@@ -38,6 +38,7 @@ enum { SLAM_PREFIX_BLOCKED = 0, SLAM_PREFIX_REFERENCE = 1 };
 enum { SLAM_RESAMPLE_MULTINOMIAL = 0, SLAM_RESAMPLE_SYSTEMATIC = 1 };
 enum { SLAM_SORT_FULL = 0, SLAM_SORT_NONE = 1 };
 enum { SLAM_WEIGHT_LINEAR = 0, SLAM_WEIGHT_LOG = 1 };
+enum { SLAM_MAPS_DENSE = 0, SLAM_MAPS_TILED = 1 };
 enum
 {
     SLAM_RAYCAST_FAST = 0,                /* clearance-skipping search; kernel shape chosen by N */
@@ -78,6 +79,14 @@ typedef struct slam_mcl_params
                               SLAM_WEIGHT_LOG (opt-in, no reference counterpart): the weight column
                               holds sum_b log w_b and the selection of slam/mcl.cpp:157-203 runs on
                               exp(lw - max lw), max over the whole filter (all shards) */
+    int32_t map_storage;   /* SLAM mode.  SLAM_MAPS_DENSE: every particle holds rows*cols bytes and the
+                              resample deep-copies them (slam/mcl.cpp:147-155).  SLAM_MAPS_TILED (opt-in,
+                              same results): canvases are tables of 64x64 copy-on-write tiles in a
+                              shared pool; the resample copies tables, a tile is copied when a
+                              particle that shares it first writes to it */
+    int32_t reserved;
+    int64_t tile_pool_tiles; /* SLAM_MAPS_TILED: tiles (4 KiB each) in the pool; 0 = 1.5 x particles x
+                                tiles per canvas, which can never run out */
 } slam_mcl_params;
 
 const char* slam_last_error(void);
@@ -191,6 +200,10 @@ typedef struct slam_mcl_device_maps
     int64_t n_particles;
 } slam_mcl_device_maps;
 int slam_mcl_device_maps_get(slam_mcl* h, slam_mcl_device_maps* out);
+/* SLAM_MAPS_TILED: {tiles in the pool, tiles referenced after the last resample (the blank tile
+ * excluded), tiles handed out since}.  A pool that runs dry makes the call that notices it return
+ * SLAM_ERR_NOMEM (canvases are then incomplete: recreate the handle with a larger pool). */
+int slam_mcl_get_tile_stats(slam_mcl* h, int64_t out[3]);
 int slam_mcl_synchronize(slam_mcl* h);
 
 /* FakeLidar::scan (slam/fake_lidar.cpp:15-33) + raycast<int> (slam/raycast.cpp:100-141), batched

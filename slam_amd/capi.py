@@ -14,6 +14,7 @@ PREFIX_BLOCKED, PREFIX_REFERENCE = 0, 1
 RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
 SORT_FULL, SORT_NONE = 0, 1
 WEIGHT_LINEAR, WEIGHT_LOG = 0, 1
+MAPS_DENSE, MAPS_TILED = 0, 1
 RAYCAST_FAST, RAYCAST_WALK, RAYCAST_FAST_BEAM_LANES, RAYCAST_FAST_PARTICLE_LANES = 0, 1, 2, 3
 
 
@@ -40,6 +41,9 @@ class Params(ctypes.Structure):
         ("stream", ctypes.c_void_p),
         ("async_launch", ctypes.c_int32),
         ("weight_domain", ctypes.c_int32),
+        ("map_storage", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("tile_pool_tiles", ctypes.c_int64),
     ]
 
 
@@ -87,6 +91,7 @@ SYMBOLS = {
     "slam_mcl_pack_maps": (ctypes.c_int, [_P, _P, _I64, _P]),
     "slam_mcl_shard_clone_maps": (ctypes.c_int, [_P, _P, _P]),
     "slam_mcl_device_maps_get": (ctypes.c_int, [_P, _P]),
+    "slam_mcl_get_tile_stats": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_poses": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64]),
     "slam_mcl_get_weights": (ctypes.c_int, [_P, _P, _I64, _I64]),
     "slam_mcl_get_map_u8": (ctypes.c_int, [_P, _I64, _P]),

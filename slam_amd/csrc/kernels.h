@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
 // 1/1024 turn, take nearly the same number of lookups and touch the same cache lines.  Keys wrap
 // (11 bits per axis): far-apart particles that alias only cost coherence, never correctness.
 __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, const double* y, const double* th,
-                                                    int mode, uint32_t* keys, int32_t* ident)
+                                                    int mode, int key_bits, uint32_t* keys, int32_t* ident)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, 
     const int kind = mode & 15;
     const int tshift = ((mode >> 4) & 15) ? ((mode >> 4) & 15) - 1 : 2;
     const int tbits = (mode >> 8) ? (mode >> 8) : 10;
-    const int nb = (32 - tbits) >> 1;
+    const int nb = (key_bits - tbits) >> 1;  // tile bits per axis; the key has tbits + 2 nb <= key_bits bits
     const unsigned tmask = (1u << nb) - 1u;
     const unsigned tx = ((unsigned)slam_f2i(x[p]) >> tshift) & tmask;
     const unsigned ty = ((unsigned)slam_f2i(y[p]) >> tshift) & tmask;
@@ -358,7 +358,107 @@ struct WaveRay
 
 __device__ __forceinline__ uint64_t lanes_upto(int l) { return l >= 63 ? ~0ull : ((1ull << (l + 1)) - 1ull); }
 
-__device__ void ray_walk_wave(uint8_t* map, int rows, int cols, double sx, double sy, double dx, double dy, double z2,
+// Storage of one particle's canvas behind ray_walk_wave.  DenseMap: rows*cols bytes (slam::Particle::map
+// as the reference holds it).  TiledMap: copy-on-write 64x64 tiles out of a shared pool (SURVEY.md §8f
+// row 3): the table of a particle holds one tile id per 64x64 block; bit TILE_OWN says the tile is
+// referenced by this table alone and may be written in place, any other tile (tile 0 = the blank
+// canvas of 128 included) is copied to a fresh tile before its first write.  Reference counts are
+// not kept while the kernel runs: the resample step rebuilds them from the tables (k_tile_*).
+enum { TILE_SHIFT = 6, TILE_MASK = 63, TILE_BYTES = 4096, TILE_OWN = 0x40000000 };
+
+struct DenseMap
+{
+    uint8_t* base;
+    int cols;
+    __device__ __forceinline__ uint8_t load(int i, int j) const { return base[(size_t)i * (size_t)cols + (size_t)j]; }
+    // called by every lane of the wavefront; lanes with wr store
+    __device__ __forceinline__ void store(bool wr, int i, int j, uint8_t v, int)
+    {
+        if (wr) base[(size_t)i * (size_t)cols + (size_t)j] = v;
+    }
+};
+
+struct TileArgs
+{
+    uint8_t* pool;            // cap tiles of TILE_BYTES
+    int32_t* tab;             // n particles x tiles_per_map entries
+    int tiles_per_map, tcols; // tiles per canvas, tiles per canvas row
+    const int32_t* freelist;  // ids of the free tiles (as of the last collection)
+    int* ctrl;                // [0] allocation cursor into freelist, [1] number of free tiles, [2] error flag
+    int lds_entries;          // > 0: the kernel was launched with 4 * lds_entries * 4 bytes of dynamic LDS for the tables
+};
+
+struct TiledMap
+{
+    uint8_t* pool;
+    int32_t* tab;   // this particle's table in HBM
+    int32_t* ltab;  // the same table staged in LDS for the lookups (or == tab when it does not fit)
+    int tcols;
+    const int32_t* freelist;
+    int* ctrl;
+    __device__ __forceinline__ uint8_t load(int i, int j) const
+    {
+        const int id = ltab[(i >> TILE_SHIFT) * tcols + (j >> TILE_SHIFT)] & ~TILE_OWN;
+        return pool[(size_t)id * TILE_BYTES + (size_t)(((i & TILE_MASK) << TILE_SHIFT) | (j & TILE_MASK))];
+    }
+    __device__ __forceinline__ void store(bool wr, int i, int j, uint8_t v, int lane)
+    {
+        const int t = wr ? (i >> TILE_SHIFT) * tcols + (j >> TILE_SHIFT) : -1;
+        int e = wr ? ltab[t] : TILE_OWN;
+        bool need = wr && !(e & TILE_OWN);
+        uint64_t m = __ballot(need);
+        const bool any_cow = m != 0;
+        while (m)
+        {
+            // (rare once k_tile_prepare has run) one shared tile at a time: allocate, copy with the
+            // whole wavefront, repoint the table
+            const int l = __builtin_ctzll(m);
+            const int tl = __shfl(t, l, 64);
+            const int old = __shfl(e, l, 64) & ~TILE_OWN;
+            int nid = -1;
+            if (lane == 0)
+            {
+                const int pos = atomicAdd(&ctrl[0], 1);
+                if (pos < ctrl[1])
+                    nid = freelist[pos];
+                else
+                    ctrl[2] = 1;  // pool exhausted: the write is dropped, the host reports SLAM_ERR_NOMEM
+            }
+            nid = __builtin_amdgcn_readfirstlane(nid);
+            if (nid >= 0)
+            {
+                const uint4* from = reinterpret_cast<const uint4*>(pool + (size_t)old * TILE_BYTES);
+                uint4* to = reinterpret_cast<uint4*>(pool + (size_t)nid * TILE_BYTES);
+#pragma unroll
+                for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) to[q * 64 + lane] = from[q * 64 + lane];
+                if (lane == 0)
+                {
+                    tab[tl] = nid | TILE_OWN;
+                    ltab[tl] = nid | TILE_OWN;
+                }
+            }
+            if (t == tl)
+            {
+                if (nid >= 0)
+                    e = nid | TILE_OWN;
+                else
+                    wr = false;
+                need = false;
+            }
+            m = __ballot(need);
+        }
+        if (any_cow)
+        {  // the copies (and the table) before the cell stores and the next pass's loads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (wr)
+            pool[(size_t)(e & ~TILE_OWN) * TILE_BYTES + (size_t)(((i & TILE_MASK) << TILE_SHIFT) | (j & TILE_MASK))] = v;
+    }
+};
+
+template <class MAP>
+__device__ __forceinline__ void ray_walk_wave(MAP map, int rows, int cols, double sx, double sy, double dx, double dy, double z2,
                               double zmax2, const uint8_t* lut_free, const uint8_t* lut_occ, int max_iter, int lane,
                               WaveRay* out)
 {
@@ -389,9 +489,8 @@ __device__ void ray_walk_wave(uint8_t* map, int rows, int cols, double sx, doubl
         const int last_exist = (max_iter - k0 - 1) < 63 ? (max_iter - k0 - 1) : 63;
         const bool isnew = (lane <= last_exist) && !(i == qi && j == qj);  // slam/raycast.cpp:171-174
         const bool inb = slam_in_bounds(rows, cols, i, j);
-        const size_t off = (size_t)i * (size_t)cols + (size_t)j;
         uint8_t c = 255;
-        if (isnew && inb) c = map[off];
+        if (isnew && inb) c = map.load(i, j);
         const double ex = X.v - sx, ey = Y.v - sy;
         const double d2 = ex * ex + ey * ey;
         const bool far = !(d2 < z2);
@@ -418,7 +517,7 @@ __device__ void ray_walk_wave(uint8_t* map, int rows, int cols, double sx, doubl
         }
         const bool proc = isnew && lane <= lim;
         const bool wr = proc && (!far || (lane == f_far && draw_occ));
-        if (wr) map[off] = far ? lut_occ[c] : lut_free[c];
+        map.store(wr, i, j, far ? lut_occ[c] : lut_free[c], lane);
         if (!drew && f_far <= lim) drew = true;
         if (lim >= 0)
         {
@@ -442,15 +541,30 @@ __device__ void ray_walk_wave(uint8_t* map, int rows, int cols, double sx, doubl
     }
 }
 
-__global__ void __launch_bounds__(256) k_weights_S_wave(WeightArgs a)
+template <bool TILED>
+__global__ void __launch_bounds__(256) k_weights_S_wave(WeightArgs a, TileArgs ta)
 {
     __shared__ uint8_t luts[512];
+    extern __shared__ int32_t lds_tabs[];
     for (int t = threadIdx.x; t < 512; t += blockDim.x) luts[t] = a.luts[t];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= a.n) return;  // whole wavefront
-    uint8_t* map = a.grid + a.map_stride * (size_t)p;
+    DenseMap dmap = {a.grid + a.map_stride * (size_t)p, a.cols};
+    TiledMap tmap = {ta.pool, nullptr, nullptr, ta.tcols, ta.freelist, ta.ctrl};
+    if (TILED)
+    {
+        tmap.tab = ta.tab + (size_t)p * ta.tiles_per_map;
+        tmap.ltab = tmap.tab;
+        if (ta.lds_entries > 0)
+        {  // this wavefront's table, staged in LDS (only this wavefront reads or writes it)
+            tmap.ltab = lds_tabs + (threadIdx.x >> 6) * ta.lds_entries;
+            for (int t = lane; t < ta.tiles_per_map; t += 64) tmap.ltab[t] = tmap.tab[t];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
     const double px = a.x[p], py = a.y[p], pth = a.th[p];
     double s0, c0;
     dm_sincos(pth + a.stheta, &s0, &c0);
@@ -474,8 +588,12 @@ __global__ void __launch_bounds__(256) k_weights_S_wave(WeightArgs a)
         for (int q = 0; q < cnt; ++q)
         {
             WaveRay wr;
-            ray_walk_wave(map, a.rows, a.cols, sx, sy, __shfl(mydx, q, 64), __shfl(mydy, q, 64), __shfl(myz2, q, 64),
-                          a.zmax2, luts, luts + 256, a.max_iter, lane, &wr);
+            if (TILED)
+                ray_walk_wave(tmap, a.rows, a.cols, sx, sy, __shfl(mydx, q, 64), __shfl(mydy, q, 64), __shfl(myz2, q, 64),
+                              a.zmax2, luts, luts + 256, a.max_iter, lane, &wr);
+            else
+                ray_walk_wave(dmap, a.rows, a.cols, sx, sy, __shfl(mydx, q, 64), __shfl(mydy, q, 64), __shfl(myz2, q, 64),
+                              a.zmax2, luts, luts + 256, a.max_iter, lane, &wr);
             if (lane == q)
             {
                 mine.hx = wr.hx;
@@ -689,6 +807,211 @@ __global__ void __launch_bounds__(256) k_clone_maps(const uint8_t* maps, uint8_t
     const size_t n16 = stride / 16;
     for (size_t t = (size_t)blockIdx.y * blockDim.x + threadIdx.x; t < n16; t += (size_t)gridDim.y * blockDim.x)
         to[t] = from[t];
+}
+
+// ---- tiled canvases: table gather at resample, collection of unreferenced tiles, import / export ----
+// Resample (slam/mcl.cpp:147-155 without the deep copy): new table p = old table src[p].  A tile stays
+// owned only if its source owned it and was selected exactly once (mult[src] == 1); any other
+// tile is shared or treated as shared (at worst one needless copy later).  Every referenced tile is
+// marked with this collection's number (plain stores: no read-modify-write on the hot tiles that
+// thousands of tables share, and no clearing of the marks between collections).
+__global__ void __launch_bounds__(256) k_tile_mult(const int32_t* src, int64_t n, int* mult)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) atomicAdd(&mult[src[k]], 1);
+}
+
+__global__ void __launch_bounds__(256) k_tab_gather(const int32_t* tab, int32_t* tab2, const int32_t* src, int T,
+                                                    const int* mult, int* ref, int live)
+{
+    const size_t p = blockIdx.x;
+    const int s = src[p];
+    const int32_t* from = tab + (size_t)s * T;
+    int32_t* to = tab2 + p * T;
+    const bool single = mult[s] == 1;
+    for (int t = threadIdx.x; t < T; t += blockDim.x)
+    {
+        const int e = from[t];
+        const int id = e & ~TILE_OWN;
+        to[t] = single ? e : id;
+        if (id) ref[id] = live;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tile_count(const int32_t* tab, int64_t total, int* ref)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const int id = tab[k] & ~TILE_OWN;
+    if (id) atomicAdd(&ref[id], 1);
+}
+
+// (general collection, after k_tile_count) own what is referenced once.  The counts double as marks
+// for k_tile_free: a referenced tile's count is replaced by `live` (negative: never a count).
+__global__ void __launch_bounds__(256) k_tile_own(int32_t* tab, int64_t total, int* ref, int live)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const int id = tab[k] & ~TILE_OWN;
+    if (!id) return;
+    const int c = ref[id];
+    // c is a count (1 = exclusive) or already `live` (another entry of a shared tile got here first)
+    tab[k] = (c == 1) ? (id | TILE_OWN) : id;
+    if (c != live) ref[id] = live;
+}
+
+// free list = every tile but the blank one whose mark is not `live` (order irrelevant).  8192 ids per
+// block and ONE atomic per block on the count: it is a single address, and a pool is mostly free.
+__global__ void __launch_bounds__(256) k_tile_free(const int* ref, int live, int cap, int32_t* freelist, int* ctrl)
+{
+    __shared__ int cnt_s, base_s;
+    if (threadIdx.x == 0) cnt_s = 0;
+    __syncthreads();
+    const int id0 = blockIdx.x * 8192 + threadIdx.x;
+    uint32_t mask = 0;
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q)
+    {
+        const int id = id0 + q * 256;
+        if (id >= 1 && id < cap && ref[id] != live)
+        {
+            mask |= 1u << q;
+            ++mine;
+        }
+    }
+    int at = mine ? atomicAdd(&cnt_s, mine) : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) base_s = cnt_s ? atomicAdd(&ctrl[1], cnt_s) : 0;
+    __syncthreads();
+    at += base_s;
+    for (int q = 0; q < 32; ++q)
+        if (mask & (1u << q)) freelist[at++] = id0 + q * 256;
+}
+
+// Before a weighting pass: every tile a particle may write (within `range` cells of its sensor) that
+// it does not own yet is copied to a fresh tile, instead of one at a time inside k_weights_S_wave.
+// k_tile_plan: one block per particle lists those tiles and takes ONE range of the free list for
+// them (a single atomic per particle: the allocation cursor is one address).  k_tile_copy: one
+// block per listed tile copies it and repoints the table.  Conservative in both directions is
+// fine: a tile copied needlessly costs 4 KiB, a tile missed is copied by the kernel.
+struct TilePlan
+{
+    int32_t *wl_p, *wl_t;  // work list, indexed like the free list: particle and tile slot (wl_p < 0: nothing to do)
+};
+
+__global__ void __launch_bounds__(256) k_tile_plan(int64_t n, const double* x, const double* y, const double* th, double sd,
+                                                   double stheta, double range, int rows, int cols, int side, TileArgs ta,
+                                                   TilePlan pl)
+{
+    __shared__ int cnt_s, base_s;
+    const int64_t p = blockIdx.x;
+    if (threadIdx.x == 0) cnt_s = 0;
+    __syncthreads();
+    double s, c;
+    dm_sincos(th[p] + stheta, &s, &c);
+    const double sc = x[p] + c * sd;                           // sensor column
+    const double sr = ((double)rows - (y[p] + s * sd)) - 1.0;  // sensor row
+    const bool sane = dm_fabs(sc) < 1.0e9 && dm_fabs(sr) < 1.0e9;
+    const int half = side >> 1;
+    const int trows = ta.tiles_per_map / ta.tcols;
+    const int32_t* tab_p = ta.tab + (size_t)p * ta.tiles_per_map;
+    int mine_t[4], mine_i[4], nmine = 0;  // side <= 31 keeps this within 4 per thread; larger squares loop further
+    for (int q = threadIdx.x; q < side * side; q += blockDim.x)
+    {
+        const int ti = (slam_f2i(sr) >> TILE_SHIFT) - half + q / side;
+        const int tj = (slam_f2i(sc) >> TILE_SHIFT) - half + q % side;
+        bool need = sane && ti >= 0 && tj >= 0 && ti < trows && tj < ta.tcols;
+        if (need)
+        {
+            const double r0 = (double)(ti << TILE_SHIFT), c0 = (double)(tj << TILE_SHIFT);
+            const double dr = sr < r0 ? r0 - sr : (sr > r0 + 64.0 ? sr - (r0 + 64.0) : 0.0);
+            const double dc = sc < c0 ? c0 - sc : (sc > c0 + 64.0 ? sc - (c0 + 64.0) : 0.0);
+            need = dr * dr + dc * dc <= range * range && !(tab_p[ti * ta.tcols + tj] & TILE_OWN);
+        }
+        if (need && nmine < 4)
+        {
+            mine_t[nmine] = ti * ta.tcols + tj;
+            mine_i[nmine] = atomicAdd(&cnt_s, 1);
+            ++nmine;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base_s = cnt_s ? atomicAdd(&ta.ctrl[0], cnt_s) : 0;
+    __syncthreads();
+    const int nfree = ta.ctrl[1];
+    for (int k = 0; k < nmine; ++k)
+    {
+        const int pos = base_s + mine_i[k];
+        if (pos < nfree)
+        {
+            pl.wl_p[pos] = (int32_t)p;
+            pl.wl_t[pos] = mine_t[k];
+        }
+        else
+            ta.ctrl[2] = 1;  // pool exhausted
+    }
+}
+
+// first = allocation cursor before k_tile_plan (ctrl[3]); block b takes free-list position first + b
+__global__ void __launch_bounds__(256) k_tile_copy(TileArgs ta, TilePlan pl)
+{
+    const int64_t pos = (int64_t)ta.ctrl[3] + blockIdx.x;
+    const int end = ta.ctrl[0] < ta.ctrl[1] ? ta.ctrl[0] : ta.ctrl[1];
+    if (pos >= end) return;
+    const int p = pl.wl_p[pos];
+    if (p < 0) return;
+    const int t = pl.wl_t[pos];
+    int32_t* tab_p = ta.tab + (size_t)p * ta.tiles_per_map;
+    const int old = tab_p[t] & ~TILE_OWN;
+    const int nid = ta.freelist[pos];
+    const uint4* from = reinterpret_cast<const uint4*>(ta.pool + (size_t)old * TILE_BYTES);
+    uint4* to = reinterpret_cast<uint4*>(ta.pool + (size_t)nid * TILE_BYTES);
+    to[threadIdx.x] = from[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        tab_p[t] = nid | TILE_OWN;
+        pl.wl_p[pos] = -1;
+    }
+}
+
+__global__ void k_tile_mark(int* ctrl) { ctrl[3] = ctrl[0] < ctrl[1] ? ctrl[0] : ctrl[1]; }
+
+// dense rows x cols canvas of one particle out of its tiles
+__global__ void __launch_bounds__(256) k_untile(const uint8_t* pool, const int32_t* tab_p, int tcols, int rows, int cols,
+                                                uint8_t* out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (int64_t)rows * cols) return;
+    const int i = (int)(k / cols), j = (int)(k - (int64_t)i * cols);
+    const int id = tab_p[(i >> TILE_SHIFT) * tcols + (j >> TILE_SHIFT)] & ~TILE_OWN;
+    out[k] = pool[(size_t)id * TILE_BYTES + (size_t)(((i & TILE_MASK) << TILE_SHIFT) | (j & TILE_MASK))];
+}
+
+// one block per tile of ONE particle: a fresh owned tile filled from the dense canvas (128 beyond its edges)
+__global__ void __launch_bounds__(256) k_tile_import(const uint8_t* dense, int rows, int cols, int32_t* tab_p, int tcols,
+                                                     uint8_t* pool, const int32_t* freelist, int* ctrl)
+{
+    __shared__ int nid_s;
+    const int t = blockIdx.x;
+    if (threadIdx.x == 0)
+    {
+        const int pos = atomicAdd(&ctrl[0], 1);
+        nid_s = pos < ctrl[1] ? freelist[pos] : -1;
+        if (nid_s < 0) ctrl[2] = 1;
+    }
+    __syncthreads();
+    const int nid = nid_s;
+    if (nid < 0) return;
+    const int ti = t / tcols, tj = t - ti * tcols;
+    uint8_t* to = pool + (size_t)nid * TILE_BYTES;
+    for (int q = threadIdx.x; q < TILE_BYTES; q += blockDim.x)
+    {
+        const int i = (ti << TILE_SHIFT) + (q >> TILE_SHIFT), j = (tj << TILE_SHIFT) + (q & TILE_MASK);
+        to[q] = (i < rows && j < cols) ? dense[(size_t)i * cols + j] : (uint8_t)128;
+    }
+    if (threadIdx.x == 0) tab_p[t] = nid | TILE_OWN;
 }
 
 __global__ void __launch_bounds__(256) k_fill_poses(int64_t n, double* x, double* y, double* th, double* w, double vx,

@@ -80,6 +80,16 @@ struct slam_mcl
     uint8_t* luts = nullptr;
     bool have_map = false;
     double *wlin = nullptr, *wmax = nullptr;  // SLAM_WEIGHT_LOG: exp(lw - max) of all shards, max-reduction levels
+    // SLAM_MAPS_TILED
+    bool tiled = false;
+    int tile_T = 0, tile_tc = 0;       // tiles per canvas, per canvas row
+    int64_t tile_cap = 0;              // tiles in the pool
+    uint8_t* tile_pool = nullptr;
+    int32_t *tile_tab = nullptr, *tile_tab2 = nullptr, *tile_free = nullptr;
+    int32_t *tile_wl_p = nullptr, *tile_wl_t = nullptr;  // work list of k_tile_plan / k_tile_copy
+    int *tile_ref = nullptr, *tile_ctrl = nullptr;  // ctrl: cursor, free count, error flag
+    uint8_t* tile_dense = nullptr;     // one dense canvas (import / export staging)
+    int tile_gen = 0;  // number of the last collection: a tile is referenced iff its mark equals -tile_gen
     bool maps_pending = false;  // SLAM-mode shard: poses resampled, canvases not yet (shard_select done)
     // scan
     int Bcap = 0;
@@ -156,6 +166,32 @@ int finish(slam_mcl* h)
 {
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->tiled)
+    {
+        int ctrl[3];
+        HIPCHK(hipMemcpy(ctrl, h->tile_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
+        if (ctrl[2])
+            return fail(SLAM_ERR_NOMEM, "tile pool exhausted (" + std::to_string(h->tile_cap) +
+                                            " tiles): canvases are incomplete, recreate the handle with a larger tile_pool_tiles");
+    }
+    return SLAM_OK;
+}
+
+// SLAM_MAPS_TILED: rebuild the reference counts from the tables, mark exclusively held tiles as
+// owned, list the unreferenced ones as free and restart the allocation cursor.
+int tile_collect(slam_mcl* h)
+{
+    const int64_t total = (int64_t)h->n * h->tile_T;
+    HIPCHK(hipMemsetAsync(h->tile_ref, 0, sizeof(int) * (size_t)h->tile_cap, h->stream));
+    HIPCHK(hipMemsetAsync(h->tile_ctrl, 0, 2 * sizeof(int), h->stream));  // cursor and count; the error flag stays
+    HIPCHK(hipMemsetAsync(h->tile_wl_p, 0xff, sizeof(int32_t) * (size_t)h->tile_cap, h->stream));
+    hipLaunchKernelGGL(slamk::k_tile_count, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, total,
+                       h->tile_ref);
+    hipLaunchKernelGGL(slamk::k_tile_own, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, total,
+                       h->tile_ref, -(++h->tile_gen));
+    hipLaunchKernelGGL(slamk::k_tile_free, dim3((unsigned)cdiv(h->tile_cap, 8192)), dim3(256), 0, h->stream, h->tile_ref,
+                       -h->tile_gen, (int)h->tile_cap, h->tile_free, h->tile_ctrl);
+    HIPCHK(hipGetLastError());
     return SLAM_OK;
 }
 
@@ -296,8 +332,31 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         // thread per particle beyond (SLAM_RAYCAST_* force a shape: 2 = wave, 3 = thread)
         const bool wave = h->prm.raycaster == SLAM_RAYCAST_FAST_BEAM_LANES ||
                           (h->prm.raycaster != SLAM_RAYCAST_FAST_PARTICLE_LANES && h->n < 262144);
-        if (wave)
-            hipLaunchKernelGGL(slamk::k_weights_S_wave, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
+        slamk::TileArgs ta = {h->tile_pool, h->tile_tab, h->tile_T, h->tile_tc, h->tile_free, h->tile_ctrl, 0};
+        if (h->tiled)
+        {
+            // make every tile within sensor range exclusive up front (parallel), then walk
+            const double range = a.zmax + 3.0;
+            // (bounding square in tiles; capped: what it misses is copied inside the kernel)
+            const int span = 2 * std::max(h->tile_T / h->tile_tc, h->tile_tc) + 1;
+            const int side = std::min(std::min(2 * (int)std::ceil(std::fmin(range, 1.0e6) / 64.0) + 3, span), 31);
+            const int64_t per = std::min<int64_t>((int64_t)side * side, h->tile_T);
+            const int64_t blocks = std::min<int64_t>(h->n * per, h->tile_cap);
+            slamk::TilePlan pl = {h->tile_wl_p, h->tile_wl_t};
+            hipLaunchKernelGGL(slamk::k_tile_mark, dim3(1), dim3(1), 0, h->stream, h->tile_ctrl);
+            hipLaunchKernelGGL(slamk::k_tile_plan, dim3((unsigned)h->n), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th, a.sd,
+                               a.stheta, range, h->rows, h->cols, side, ta, pl);
+            hipLaunchKernelGGL(slamk::k_tile_copy, dim3((unsigned)blocks), dim3(256), 0, h->stream, ta, pl);
+            size_t lds = 0;
+            if ((size_t)h->tile_T * 16 <= 48 * 1024)
+            {
+                ta.lds_entries = h->tile_T;
+                lds = (size_t)h->tile_T * 16;
+            }
+            hipLaunchKernelGGL(slamk::k_weights_S_wave<true>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), lds, h->stream, a, ta);
+        }
+        else if (wave)
+            hipLaunchKernelGGL(slamk::k_weights_S_wave<false>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a, ta);
         else
             hipLaunchKernelGGL(slamk::k_weights_S, dim3((unsigned)cdiv(h->n, 64)), dim3(64), 0, h->stream, a);
     }
@@ -322,6 +381,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         }
         a.lw = h->lw;
         static const int order_mode = getenv("SLAM_PL_ORDER") ? atoi(getenv("SLAM_PL_ORDER")) : 3;
+        static const int order_bits = getenv("SLAM_PL_ORDER_BITS") ? atoi(getenv("SLAM_PL_ORDER_BITS")) : 32;
         if (order_mode > 0)
         {
             if (!h->okeys)
@@ -339,9 +399,9 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 h->osort_tmp_bytes = bytes;
             }
             hipLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x,
-                               h->y, h->th, order_mode, h->okeys, h->oident);
+                               h->y, h->th, order_mode, order_bits, h->okeys, h->oident);
             size_t bytes = h->osort_tmp_bytes;
-            HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, 32,
+            HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, order_bits,
                                              h->stream));
             a.order = h->order;
         }
@@ -454,6 +514,8 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
         return fail(SLAM_ERR_STATE, "resample: shards * n_particles != global_n (sharded handles must use slam_mcl_shard_resample)");
     if (n_shards > 1 && (h->prm.sort != SLAM_SORT_NONE || h->prm.prefix_order != SLAM_PREFIX_BLOCKED))
         return fail(SLAM_ERR_STATE, "sharded resampling needs SLAM_SORT_NONE and SLAM_PREFIX_BLOCKED");
+    if (h->tiled && (n_shards > 1 || !clone_local))
+        return fail(SLAM_ERR_STATE, "SLAM_MAPS_TILED handles do not shard yet");
     if (n_shards > 1 && h->prm.mode == SLAM_MODE_SLAM && clone_local)
         return fail(SLAM_ERR_STATE, "SLAM-mode shards: use slam_mcl_shard_select + slam_mcl_shard_clone_maps");
     slamk::StateView view;
@@ -495,7 +557,24 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
     }
     std::swap(h->state, h->state2);
     h->bind();
-    if (h->prm.mode == SLAM_MODE_SLAM && clone_local)
+    if (h->prm.mode == SLAM_MODE_SLAM && clone_local && h->tiled)
+    {
+        // slam/mcl.cpp:147-155 without the deep copy: the selected particles share their source's
+        // tiles until one of them writes
+        slam_mcl::Span span(h, G_CLONE);
+        int* mult = reinterpret_cast<int*>(h->tile_wl_t);  // free between passes; n <= tile_cap entries
+        HIPCHK(hipMemsetAsync(mult, 0, sizeof(int) * (size_t)n, h->stream));
+        HIPCHK(hipMemsetAsync(h->tile_ctrl, 0, 2 * sizeof(int), h->stream));
+        ++h->tile_gen;
+        hipLaunchKernelGGL(slamk::k_tile_mult, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, h->src, n, mult);
+        hipLaunchKernelGGL(slamk::k_tab_gather, dim3((unsigned)n), dim3(256), 0, h->stream, h->tile_tab, h->tile_tab2,
+                           h->src, h->tile_T, mult, h->tile_ref, -h->tile_gen);
+        std::swap(h->tile_tab, h->tile_tab2);
+        hipLaunchKernelGGL(slamk::k_tile_free, dim3((unsigned)cdiv(h->tile_cap, 8192)), dim3(256), 0, h->stream, h->tile_ref,
+                           -h->tile_gen, (int)h->tile_cap, h->tile_free, h->tile_ctrl);
+        HIPCHK(hipGetLastError());
+    }
+    else if (h->prm.mode == SLAM_MODE_SLAM && clone_local)
     {
         slam_mcl::Span span(h, G_CLONE);
         launch_clone(h, h->maps, h->maps2, h->src, n);
@@ -531,7 +610,9 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
                     h->grid,  h->clr,    h->maps, h->maps2,    h->luts,         h->scan_dev,
                     h->inj_normals, h->inj_uniforms, h->idx, h->perm, h->slots, h->src,   h->keys, h->keys2,
                     h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
-                    h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->wlin, h->wmax};
+                    h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->wlin, h->wmax,
+                    h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_ctrl, h->tile_dense,
+                    h->tile_wl_p, h->tile_wl_t};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (size_t l = 0; l < h->lvl_s.size(); ++l)
@@ -651,7 +732,38 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
         build_luts(t);
         if (hipMemcpy(h->luts, t, 512, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SLAM_ERR_HIP, "lut upload");
     }
-    if (!rc && h->prm.mode == SLAM_MODE_SLAM)
+    if (!rc && h->prm.map_storage != SLAM_MAPS_DENSE && h->prm.map_storage != SLAM_MAPS_TILED)
+        rc = fail(SLAM_ERR_ARG, "map_storage must be SLAM_MAPS_DENSE or SLAM_MAPS_TILED");
+    if (!rc && h->prm.mode == SLAM_MODE_SLAM && h->prm.map_storage == SLAM_MAPS_TILED)
+    {
+        h->tiled = true;
+        h->map_stride = ((size_t)h->rows * h->cols + 255) / 256 * 256;
+        h->tile_tc = (h->cols + 63) / 64;
+        h->tile_T = ((h->rows + 63) / 64) * h->tile_tc;
+        const int64_t dflt = (3 * n * h->tile_T + 1) / 2 + 1;
+        h->tile_cap = h->prm.tile_pool_tiles > 0 ? h->prm.tile_pool_tiles + 1 : dflt;  // + the blank tile 0
+        if (h->tile_cap >= (int64_t)slamk::TILE_OWN || n != h->n_glob)
+            rc = fail(SLAM_ERR_ARG, "tiled canvases: pool too large, or a shard (not supported yet)");
+        TRY(dev_alloc(&h->tile_pool, (size_t)h->tile_cap * slamk::TILE_BYTES));
+        TRY(dev_alloc(&h->tile_tab, (size_t)n * h->tile_T));
+        TRY(dev_alloc(&h->tile_tab2, (size_t)n * h->tile_T));
+        TRY(dev_alloc(&h->tile_free, (size_t)h->tile_cap));
+        TRY(dev_alloc(&h->tile_wl_p, (size_t)h->tile_cap));
+        TRY(dev_alloc(&h->tile_wl_t, (size_t)std::max<int64_t>(h->tile_cap, n)));  // doubles as the multiplicity array
+        TRY(dev_alloc(&h->tile_ref, (size_t)h->tile_cap));
+        TRY(dev_alloc(&h->tile_ctrl, 4));
+        TRY(dev_alloc(&h->tile_dense, h->map_stride));
+        if (!rc)
+        {
+            // slam/mcl.cpp:30: every canvas is the blank tile 0 (128), nothing else is referenced
+            bool ok = hipMemsetAsync(h->tile_pool, 128, slamk::TILE_BYTES, h->stream) == hipSuccess &&
+                      hipMemsetAsync(h->tile_tab, 0, sizeof(int32_t) * (size_t)n * h->tile_T, h->stream) == hipSuccess &&
+                      hipMemsetAsync(h->tile_ctrl, 0, 4 * sizeof(int), h->stream) == hipSuccess;
+            if (!ok) rc = fail(SLAM_ERR_HIP, "tile pool initialisation");
+            TRY(tile_collect(h));
+        }
+    }
+    else if (!rc && h->prm.mode == SLAM_MODE_SLAM)
     {
         h->map_stride = ((size_t)h->rows * h->cols + 255) / 256 * 256;
         TRY(dev_alloc(&h->maps, h->map_stride * (size_t)n));
@@ -763,6 +875,21 @@ SLAM_API int slam_mcl_set_maps_u8(slam_mcl* h, const uint8_t* maps, int64_t firs
     if (!maps || first < 0 || count < 0 || first + count > h->n) return fail(SLAM_ERR_ARG, "set_maps_u8: bad range");
     const size_t bytes = (size_t)h->rows * h->cols;
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->tiled)
+    {
+        // drop the old tiles of these particles, then import every canvas as fresh owned tiles
+        HIPCHK(hipMemsetAsync(h->tile_tab + (size_t)first * h->tile_T, 0, sizeof(int32_t) * (size_t)count * h->tile_T, h->stream));
+        if ((rc = tile_collect(h))) return rc;
+        for (int64_t k = 0; k < count; ++k)
+        {
+            HIPCHK(hipMemcpyAsync(h->tile_dense, maps + bytes * (size_t)k, bytes, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(slamk::k_tile_import, dim3((unsigned)h->tile_T), dim3(256), 0, h->stream, h->tile_dense, h->rows,
+                               h->cols, h->tile_tab + (size_t)(first + k) * h->tile_T, h->tile_tc, h->tile_pool, h->tile_free,
+                               h->tile_ctrl);
+            HIPCHK(hipStreamSynchronize(h->stream));  // tile_dense is reused
+        }
+        return finish(h);
+    }
     HIPCHK(hipMemcpy2D(h->maps + h->map_stride * (size_t)first, h->map_stride, maps, bytes, bytes, (size_t)count,
                        hipMemcpyHostToDevice));
     return SLAM_OK;
@@ -913,7 +1040,7 @@ SLAM_API int slam_mcl_pack_maps(slam_mcl* h, const int32_t* local_idx_dev, int64
 {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "pack_maps: SLAM mode only");
+    if (h->prm.mode != SLAM_MODE_SLAM || h->tiled) return fail(SLAM_ERR_STATE, "pack_maps: SLAM mode with dense canvases only");
     if (count < 0 || count > 2147483647LL || (count > 0 && (!local_idx_dev || !out_dev)))
         return fail(SLAM_ERR_ARG, "pack_maps: bad count or null pointer");
     if (count > 0)
@@ -942,9 +1069,25 @@ SLAM_API int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, con
     return maybe_finish(h);
 }
 
+SLAM_API int slam_mcl_get_tile_stats(slam_mcl* h, int64_t out[3])
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out) return fail(SLAM_ERR_ARG, "null");
+    if (!h->tiled) return fail(SLAM_ERR_STATE, "get_tile_stats: the handle holds dense canvases");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int ctrl[3];
+    HIPCHK(hipMemcpy(ctrl, h->tile_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
+    out[0] = h->tile_cap - 1;
+    out[1] = h->tile_cap - 1 - ctrl[1];
+    out[2] = ctrl[0] < ctrl[1] ? ctrl[0] : ctrl[1];
+    return SLAM_OK;
+}
+
 SLAM_API int slam_mcl_device_maps_get(slam_mcl* h, slam_mcl_device_maps* out)
 {
     if (!h || !out) return fail(SLAM_ERR_ARG, "null");
+    if (h->tiled) return fail(SLAM_ERR_STATE, "device_maps_get: the handle holds tiled canvases");
     out->maps_dev = h->maps;
     out->idx_dev = h->idx;
     out->map_stride = (int64_t)h->map_stride;
@@ -992,6 +1135,16 @@ SLAM_API int slam_mcl_get_map_u8(slam_mcl* h, int64_t particle, uint8_t* map)
     if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "get_map_u8 is for SLAM mode");
     if (!map || particle < 0 || particle >= h->n) return fail(SLAM_ERR_ARG, "get_map_u8: bad particle");
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->tiled)
+    {
+        const int64_t cells = (int64_t)h->rows * h->cols;
+        hipLaunchKernelGGL(slamk::k_untile, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, h->stream, h->tile_pool,
+                           h->tile_tab + (size_t)particle * h->tile_T, h->tile_tc, h->rows, h->cols, h->tile_dense);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(map, h->tile_dense, (size_t)cells, hipMemcpyDeviceToHost));
+        return SLAM_OK;
+    }
     HIPCHK(hipMemcpy(map, h->maps + h->map_stride * (size_t)particle, (size_t)h->rows * h->cols, hipMemcpyDeviceToHost));
     return SLAM_OK;
 }

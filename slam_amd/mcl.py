@@ -35,7 +35,7 @@ class Filter:
     def __init__(self, n_particles, rows, cols, mode=capi.MODE_LOCALIZATION, device=0, seed=0x5EED0001,
                  noise=capi.NOISE_PHILOX, prefix_order=capi.PREFIX_BLOCKED, resampler=capi.RESAMPLE_MULTINOMIAL,
                  sort=capi.SORT_FULL, raycaster=capi.RAYCAST_FAST, global_first=0, global_n=0, stream=None,
-                 async_launch=False, weight_domain=capi.WEIGHT_LINEAR):
+                 async_launch=False, weight_domain=capi.WEIGHT_LINEAR, map_storage=capi.MAPS_DENSE, tile_pool_tiles=0):
         self.lib = capi.load_library()
         p = capi.Params()
         p.struct_size = ctypes.sizeof(capi.Params)
@@ -54,6 +54,8 @@ class Filter:
         p.stream = stream
         p.async_launch = 1 if async_launch else 0
         p.weight_domain = weight_domain
+        p.map_storage = map_storage
+        p.tile_pool_tiles = tile_pool_tiles
         self.params = p
         self.n = int(n_particles)
         self.global_n = int(global_n) if global_n else int(n_particles)
@@ -234,6 +236,11 @@ class Filter:
         out = np.zeros(3, dtype=np.int64)
         check(self.lib.slam_mcl_get_stats(self._h, ptr(out)), self.lib)
         return {"cells_read": int(out[0]), "cells_written": int(out[1]), "steps": int(out[2])}
+
+    def tile_stats(self):
+        out = np.zeros(3, dtype=np.int64)
+        check(self.lib.slam_mcl_get_tile_stats(self._h, ptr(out)), self.lib)
+        return {"pool": int(out[0]), "live": int(out[1]), "allocated_since": int(out[2])}
 
     def profile(self, enable=True):
         check(self.lib.slam_mcl_profile(self._h, 1 if enable else 0), self.lib)

@@ -34,8 +34,20 @@ def test_library_exports_every_declared_symbol():
 def test_params_struct_layout_matches_header():
     from slam_amd import capi
 
-    # field order/sizes of slam_mcl_params in include/slam_hip.h
-    assert ctypes.sizeof(capi.Params) == 88
+    # field order/sizes of slam_mcl_params in include/slam_hip.h, as a C compiler lays it out
+    import subprocess
+    import tempfile
+
+    fields = [f[0] for f in capi.Params._fields_]
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"slam_hip.h\"\nint main(void){printf(\"%zu\", sizeof(slam_mcl_params));" + \
+        "".join(f'printf(" %zu", offsetof(slam_mcl_params, {f}));' for f in fields) + "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "l.c"), os.path.join(d, "l")
+        open(src, "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, src], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(capi.Params) == 104
+    assert got[1:] == [getattr(capi.Params, f).offset for f in fields]
 
 
 def test_no_silent_cpu_fallback():

@@ -334,6 +334,73 @@ def test_slam_loop_like_the_reference_benchmark(sa):
     f.close()
 
 
+# ---- tiled copy-on-write canvases: same results as the dense storage -----------
+def test_tiled_canvases_match_dense_and_oracle(sa):
+    """The grid-SLAM loop with canvases held as tables of 64x64 copy-on-write tiles: poses, weights,
+    selection and every canvas equal the oracle's (hence the dense storage's) at every step; the pool
+    holds far fewer tiles than dense canvases would, because tiles out of sensor range stay shared."""
+    rng = np.random.default_rng(61)
+    N, B, rows, cols, zmax, seed = 96, 60, 450, 700, 120.0, 0x711E      # canvas not a multiple of 64
+    free = orc.load_map("map")
+    ang, dist = orc.make_scan(free, [400.0, 400.0, np.pi / 90], OFFSET, B, max_dist=zmax)
+    x, y, th = cloud(rng, N, cols / 2, rows / 2, sxy=4.0, sth=0.2, th0=np.pi / 2)
+    odom = [0.1, 3.0, 0.05]
+    T = ((rows + 63) // 64) * ((cols + 63) // 64)
+    f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed, map_storage=sa.capi.MAPS_TILED)
+    f.set_poses(x, y, th)
+    assert f.tile_stats() == {"pool": (3 * N * T + 1) // 2, "live": 0, "allocated_since": 0}
+    assert np.all(f.map_of(5) == 128)
+    state, maps = (x, y, th), np.full((N, rows, cols), 128, np.uint8)
+    for step in range(5):
+        f.predict(odom, ALPHAS)
+        f.update(ang, dist, 5.0, zmax, OFFSET)
+        ox, oy, oth = orc.predict(*state, odom, ALPHAS, orc.philox_normals(seed, step, 0, N), math=orc.DET)
+        ow, _ = orc.update_weights(ox, oy, oth, maps, ang, dist, 5.0, zmax, OFFSET, slam_mode=True, math=orc.DET)
+        idx, _, _ = orc.resample(ow, orc.philox_uniforms(seed, step, 0, N), orc.ORDER_BLOCKED)
+        perm = orc.sort_order(ow[idx], 0)
+        src = idx[perm]
+        state, maps = (ox[src], oy[src], oth[src]), maps[src].copy()
+        assert np.array_equal(f.last_indices(), idx), f"step {step}"
+        for q in range(3):
+            assert_bits(f.poses()[q], state[q], f"pose column {q}, step {step}")
+        assert_bits(f.weights(), ow[src], "weights")
+        for p in range(0, N, 5):
+            assert np.array_equal(f.map_of(p), maps[p]), f"canvas {p}, step {step}"
+        st = f.tile_stats()
+        assert 0 < st["live"] < N * T / 2, st      # only the tiles within range of the sensor were ever written
+    # repeated weighting without a resample: owned tiles are written in place, shared ones copied once
+    before = f.tile_stats()
+    for it in range(2):
+        f.update_weights(ang, dist, 5.0, zmax, OFFSET)
+        ow, _ = orc.update_weights(*state, maps, ang, dist, 5.0, zmax, OFFSET, slam_mode=True, math=orc.DET)
+        assert_bits(f.weights(), ow, f"repeat {it}")
+        if it == 0:
+            first = f.tile_stats()["allocated_since"]
+    assert f.tile_stats()["allocated_since"] == first > 0 and before["allocated_since"] == 0
+    for p in range(0, N, 7):
+        assert np.array_equal(f.map_of(p), maps[p])
+    # set_maps / map_of round trip through the tiles
+    custom = rng.integers(0, 256, size=(3, rows, cols), dtype=np.uint8)
+    f.set_maps(custom, first=10)
+    for k in range(3):
+        assert np.array_equal(f.map_of(10 + k), custom[k])
+    assert np.array_equal(f.map_of(9), maps[9]) and np.array_equal(f.map_of(13), maps[13])
+    f.close()
+
+
+def test_tiled_pool_exhaustion_is_reported(sa):
+    N, B, rows, cols = 32, 90, 400, 400
+    free = orc.load_map("map")
+    ang, dist = orc.make_scan(free, [400.0, 400.0, np.pi / 90], OFFSET, B)
+    f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, map_storage=sa.capi.MAPS_TILED, tile_pool_tiles=40)
+    with pytest.raises(RuntimeError, match="tile pool exhausted"):
+        f.update(ang, dist, 5.0, 500.0, OFFSET)
+    f.close()
+    with pytest.raises(RuntimeError):   # shards of tiled canvases are not built yet: refused, not wrong
+        sa.Filter(64, rows, cols, mode=sa.capi.MODE_SLAM, map_storage=sa.capi.MAPS_TILED, sort=sa.capi.SORT_NONE,
+                  global_first=0, global_n=128)
+
+
 @pytest.mark.parametrize("order", ["blocked", "reference"])
 def test_localization_loop(sa, order):
     rng = np.random.default_rng(99)

@@ -22,8 +22,12 @@ m01 = np.ascontiguousarray(free, dtype=np.uint8)
 capi.check(capi.load_library().slam_fake_lidar_scan(0, capi.ptr(m01), m01.shape[0], m01.shape[1], capi.ptr(sp), len(poses), 0.0, 2 * np.pi, 500.0, B, capi.ptr(hits)))
 ang = np.arange(B) * (2 * np.pi / B) - np.pi
 scans = [(ang, np.where(hits[k, :, 0] != -1, np.hypot(hits[k, :, 1] - sp[k, 1], hits[k, :, 0] - sp[k, 0]), 500.0)) for k in range(len(poses))]
-for name, rc in (("wave", capi.RAYCAST_FAST_BEAM_LANES), ("thread", capi.RAYCAST_FAST_PARTICLE_LANES)):
-    f = sa.Filter(N, C, C, mode=capi.MODE_SLAM, raycaster=rc)
+CR = int(os.environ.get("SB_ROWS", C))
+variants = [("wave", capi.RAYCAST_FAST_BEAM_LANES, capi.MAPS_DENSE), ("tiled", capi.RAYCAST_FAST, capi.MAPS_TILED)]
+if os.environ.get("SB_THREAD", "0") == "1":
+    variants.append(("thread", capi.RAYCAST_FAST_PARTICLE_LANES, capi.MAPS_DENSE))
+for name, rc, storage in variants:
+    f = sa.Filter(N, CR, C, mode=capi.MODE_SLAM, raycaster=rc, map_storage=storage)
     f.profile(True)
     for k in range(len(scans)):
         f.predict(odom, alphas)
@@ -34,8 +38,9 @@ for name, rc in (("wave", capi.RAYCAST_FAST_BEAM_LANES), ("thread", capi.RAYCAST
     f.synchronize()
     dt = (time.perf_counter() - t0) / (len(scans) - 4) * 1e3
     km = f.kernel_ms(); st = f.stats()
-    print(f"{name:7s} N={N} canvas={C}: {dt:8.3f} ms/step wall;", {k: round(v[0] / max(v[1], 1), 3) for k, v in km.items()},
-          f"cells_read/ray={st['cells_read'] / (N * B):.1f} written/ray={st['cells_written'] / (N * B):.1f}", flush=True)
+    print(f"{name:7s} N={N} canvas={CR}x{C}: {dt:8.3f} ms/step wall;", {k: round(v[0] / max(v[1], 1), 3) for k, v in km.items()},
+          f"cells_read/ray={st['cells_read'] / (N * B):.1f} written/ray={st['cells_written'] / (N * B):.1f}",
+          f.tile_stats() if storage == capi.MAPS_TILED else "", flush=True)
     f.close()
 if os.environ.get("SB_CPU", "1") == "1":
     import _oracle as orc
