@@ -21,7 +21,8 @@ def test_shim_builds_against_the_c_abi_only():
 
 
 @pytest.mark.gpu
-def test_cpp_shim_matches_python_path(tmp_path):
+@pytest.mark.parametrize("storage", ["dense", "tiled"])
+def test_cpp_shim_matches_python_path(tmp_path, storage):
     import slam_amd as sa
     from slam_amd import capi
 
@@ -29,7 +30,7 @@ def test_cpp_shim_matches_python_path(tmp_path):
     raw = tmp_path / "map.raw"
     free.tofile(raw)
     iters, seed = 4, 0x1234ABCD
-    env = dict(os.environ, SLAM_SEED=str(seed))
+    env = dict(os.environ, SLAM_SEED=str(seed), SLAM_MAPS=storage)   # the shim's storage must not change any result
     out = subprocess.run([EXE, str(raw), str(free.shape[0]), str(free.shape[1]), str(iters)], check=True, env=env,
                          capture_output=True, text=True, timeout=300).stdout.splitlines()
     parts = np.array([[int(t, 16) for t in ln.split()[1:]] for ln in out if ln.startswith("P ")], dtype=np.uint64)
