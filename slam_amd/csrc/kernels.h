@@ -457,6 +457,43 @@ struct TiledMap
     }
 };
 
+// One pass = 64 consecutive samples of a ray: positions, cells and the cells' bytes (load issued).
+struct WavePass
+{
+    slam_axis X, Y;
+    int i, j;
+    int last_exist;
+    bool isnew, inb;
+    uint8_t c;
+};
+
+template <class MAP>
+__device__ __forceinline__ void wave_pass_prepare(const MAP& map, int rows, int cols, const slam_axis& Xb, const slam_axis& Yb,
+                                                  int pi, int pj, double dx, double dy, int k0, int max_iter, int lane,
+                                                  WavePass* ps)
+{
+    ps->X = Xb;
+    ps->Y = Yb;
+    slam_advance(&ps->X, &ps->Y, dx, dy, lane + 1);  // sample k0 + lane + 1, exact
+    slam_cell_of(rows, ps->X.v, ps->Y.v, &ps->i, &ps->j);
+    int qi = __shfl_up(ps->i, 1, 64), qj = __shfl_up(ps->j, 1, 64);
+    if (lane == 0)
+    {
+        qi = pi;
+        qj = pj;
+    }
+    ps->last_exist = (max_iter - k0 - 1) < 63 ? (max_iter - k0 - 1) : 63;
+    ps->isnew = (lane <= ps->last_exist) && !(ps->i == qi && ps->j == qj);  // slam/raycast.cpp:171-174
+    ps->inb = slam_in_bounds(rows, cols, ps->i, ps->j);
+    // unconditional load (cell (0,0) stands in for samples that have no cell to read): a load under a
+    // divergent branch would have to be waited for at the join, which would serialise the two passes
+    const bool rd = ps->isnew && ps->inb;
+    ps->c = map.load(rd ? ps->i : 0, rd ? ps->j : 0);
+}
+
+// The cells of the NEXT pass are read before the current pass is resolved (its loads overlap the
+// current pass's latency): a ray's cells are distinct, so those bytes cannot be changed by the
+// current pass's writes, and if the ray ends in the current pass they are simply not used.
 template <class MAP>
 __device__ __forceinline__ void ray_walk_wave(MAP map, int rows, int cols, double sx, double sy, double dx, double dy, double z2,
                               double zmax2, const uint8_t* lut_free, const uint8_t* lut_occ, int max_iter, int lane,
@@ -474,24 +511,28 @@ __device__ __forceinline__ void ray_walk_wave(MAP map, int rows, int cols, doubl
     out->n_read = out->n_written = 0;
     out->n_steps = (unsigned)max_iter;
     const bool draw_occ = (z2 != zmax2);  // slam/raycast.cpp:205
-    for (int k0 = 0; k0 < max_iter; k0 += 64)
+    if (max_iter <= 0) return;
+    WavePass cur;
+    wave_pass_prepare(map, rows, cols, Xb, Yb, pi, pj, dx, dy, 0, max_iter, lane, &cur);
+    for (int k0 = 0;; k0 += 64)
     {
-        slam_axis X = Xb, Y = Yb;
-        slam_advance(&X, &Y, dx, dy, lane + 1);  // sample k0 + lane + 1, exact
-        int i, j;
-        slam_cell_of(rows, X.v, Y.v, &i, &j);
-        int qi = __shfl_up(i, 1, 64), qj = __shfl_up(j, 1, 64);
-        if (lane == 0)
+        const bool more = cur.last_exist == 63 && k0 + 64 < max_iter;
+        WavePass nxt = cur;
+        if (more)
         {
-            qi = pi;
-            qj = pj;
+            Xb.v = __shfl(cur.X.v, 63, 64);
+            Xb.inc = __shfl(cur.X.inc, 63, 64);
+            Xb.rem = __shfl(cur.X.rem, 63, 64);
+            Yb.v = __shfl(cur.Y.v, 63, 64);
+            Yb.inc = __shfl(cur.Y.inc, 63, 64);
+            Yb.rem = __shfl(cur.Y.rem, 63, 64);
+            wave_pass_prepare(map, rows, cols, Xb, Yb, __shfl(cur.i, 63, 64), __shfl(cur.j, 63, 64), dx, dy, k0 + 64,
+                              max_iter, lane, &nxt);
         }
-        const int last_exist = (max_iter - k0 - 1) < 63 ? (max_iter - k0 - 1) : 63;
-        const bool isnew = (lane <= last_exist) && !(i == qi && j == qj);  // slam/raycast.cpp:171-174
-        const bool inb = slam_in_bounds(rows, cols, i, j);
-        uint8_t c = 255;
-        if (isnew && inb) c = map.load(i, j);
-        const double ex = X.v - sx, ey = Y.v - sy;
+        const int i = cur.i, j = cur.j, last_exist = cur.last_exist;
+        const bool isnew = cur.isnew, inb = cur.inb;
+        const uint8_t c = cur.c;
+        const double ex = cur.X.v - sx, ey = cur.Y.v - sy;
         const double d2 = ex * ex + ey * ey;
         const bool far = !(d2 < z2);
         const uint64_t m_new = __ballot(isnew);
@@ -510,8 +551,8 @@ __device__ __forceinline__ void ray_walk_wave(MAP map, int rows, int cols, doubl
         if (lim > last_exist) lim = last_exist;
         if (!found && f_hit <= lim)
         {
-            out->hx = __shfl(X.v, f_hit, 64);
-            out->hy = __shfl(Y.v, f_hit, 64);
+            out->hx = __shfl(cur.X.v, f_hit, 64);
+            out->hy = __shfl(cur.Y.v, f_hit, 64);
             out->hcell = __shfl(i, f_hit, 64) * cols + __shfl(j, f_hit, 64);
             found = true;
         }
@@ -529,15 +570,8 @@ __device__ __forceinline__ void ray_walk_wave(MAP map, int rows, int cols, doubl
             out->n_steps = (unsigned)(k0 + term + 1);
             return;
         }
-        if (last_exist < 63) return;  // max_iter reached (the reference would spin here)
-        Xb.v = __shfl(X.v, 63, 64);
-        Xb.inc = __shfl(X.inc, 63, 64);
-        Xb.rem = __shfl(X.rem, 63, 64);
-        Yb.v = __shfl(Y.v, 63, 64);
-        Yb.inc = __shfl(Y.inc, 63, 64);
-        Yb.rem = __shfl(Y.rem, 63, 64);
-        pi = __shfl(i, 63, 64);
-        pj = __shfl(j, 63, 64);
+        if (!more) return;  // max_iter reached (the reference would spin here)
+        cur = nxt;
     }
 }
 
