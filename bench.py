@@ -136,7 +136,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_SHARDED=1: rehearse the multi-GPU code path (RCCL init, staged all-gather, sharded
+    # resample) with whatever world size the launcher gives, one rank included
+    force_sharded = os.environ.get("BENCH_FORCE_SHARDED", "0") == "1"
+    if world > 1 or (force_sharded and "RANK" in os.environ):
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -148,7 +151,8 @@ def main():
     ang, dscan = scans[0]
     step_no = [0]
 
-    if world == 1:
+    sharded = world > 1 or force_sharded
+    if not sharded:
         f = sa.Filter(n_loc, rows, cols, device=local_rank, seed=SEED, stream=stream, async_launch=True)
         f.set_map(grid)
         step_predict = lambda: f.predict(ODOM, ALPHAS)
@@ -156,7 +160,7 @@ def main():
     else:
         shard = HipShard(n_loc, rows, cols, rank, world, local_rank, SEED, stream=stream, async_launch=True)
         shard.set_map(grid)
-        sf = ShardedFilter(shard, world=world)
+        sf = ShardedFilter(shard, world=world, always_collective=force_sharded and dist.is_initialized())
         f = shard.f
         step_predict = lambda: sf.predict(ODOM, ALPHAS)
         upd = lambda a, d: sf.update(a, d, STDDEV, MAX_DIST, OFFSET)
@@ -238,9 +242,9 @@ def main():
             "config": {
                 "workload": f"BASELINE configs[1]: MCL localization, floor_plan 1297x599, {n_loc} particles x {B} beams per GPU, "
                             f"max_dist {MAX_DIST:g}, sigma {STDDEV:g}, full step = predict + update (weights, running sum, "
-                            f"multinomial select, {'sort, ' if world == 1 else ''}gather)",
+                            f"multinomial select, {'' if sharded else 'sort, '}gather)",
                 "particles_per_gpu": n_loc, "beams": B, "map": "floor_plan", "noise": "philox4x32-10",
-                "resampling": "multinomial (reference rule)" + ("" if world == 1 else ", global over all ranks via one all-gather"),
+                "resampling": "multinomial (reference rule)" + (", global over all ranks via one all-gather" if sharded else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -254,7 +258,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(free, ang, dscan, B)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

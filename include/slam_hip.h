@@ -168,7 +168,8 @@ typedef struct slam_mcl_device_state
 int slam_mcl_device_state_get(slam_mcl* h, slam_mcl_device_state* out);
 
 /* Sharded resampling for one-process-per-GPU drivers.  Every shard holds
- * n_particles = global_n / n_shards particles (a multiple of 64).  After update_weights the caller
+ * n_particles = global_n / n_shards particles (any count: the canonical blocked order runs over the
+ * global index, so its 64-chunks may straddle shards).  After update_weights the caller
  * all-gathers the packed state buffers of all shards, in shard order, into gathered_state_dev
  * ([n_shards][4][n_particles] doubles, i.e. the plain concatenation all-gather produces).  This call
  * then builds the running sum of ALL weights in the canonical blocked order, draws this shard's

@@ -1021,7 +1021,6 @@ SLAM_API int slam_mcl_shard_resample(slam_mcl* h, const double* gathered_state_d
     int rc = check_handle(h);
     if (rc) return rc;
     if (!gathered_state_dev || n_shards < 1) return fail(SLAM_ERR_ARG, "shard_resample: null buffer or n_shards < 1");
-    if (h->n % 64) return fail(SLAM_ERR_STATE, "sharded resampling needs n_particles % 64 == 0 on every shard");
     if ((rc = do_resample(h, gathered_state_dev, n_shards))) return rc;
     return maybe_finish(h);
 }
@@ -1034,7 +1033,6 @@ SLAM_API int slam_mcl_shard_select(slam_mcl* h, const double* gathered_state_dev
     if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "shard_select is the SLAM-mode form of shard_resample");
     if (h->prm.sort != SLAM_SORT_NONE || h->prm.prefix_order != SLAM_PREFIX_BLOCKED)
         return fail(SLAM_ERR_STATE, "sharded resampling needs SLAM_SORT_NONE and SLAM_PREFIX_BLOCKED");
-    if (h->n % 64) return fail(SLAM_ERR_STATE, "sharded resampling needs n_particles % 64 == 0 on every shard");
     if ((rc = do_resample(h, gathered_state_dev, n_shards, false))) return rc;
     h->maps_pending = true;
     return maybe_finish(h);

@@ -66,9 +66,10 @@ class HipShard:
 class ShardedFilter:
     """The filter step over `world` ranks.  `backend` is the local shard (HipShard in production)."""
 
-    def __init__(self, backend, world=None, group=None):
+    def __init__(self, backend, world=None, group=None, always_collective=False):
         self.b = backend
         self.group = group
+        self.always_collective = always_collective  # issue the all-gather even for one rank (rehearsal)
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self._gathered = backend.new_gather_buffer(self.world)
         self._stage = None
@@ -79,7 +80,7 @@ class ShardedFilter:
     def update(self, angles, dists, stddev, max_dist, offset=(0.0, 0.0, 0.0)):
         self.b.update_weights(angles, dists, stddev, max_dist, offset)
         local = self.b.packed_state()
-        if self.world > 1:
+        if self.world > 1 or self.always_collective:
             # the one exchange step of the path: all-gather of [x | y | theta | w] of every shard.
             # The library's buffer is viewed zero-copy; it is staged through a torch-allocated
             # tensor (32 B/particle) so that RCCL only ever sees allocator-owned memory.

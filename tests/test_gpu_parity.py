@@ -544,7 +544,7 @@ def test_sharded_filter_matches_single_handle(sa, shards):
     from slam_amd.dist import HipShard, ShardedFilter
 
     rng = np.random.default_rng(31)
-    N, B, seed = 4096, 90, 0xC0FFEE
+    N, B, seed = 4200, 90, 0xC0FFEE   # shards of 2100 / 1050 particles: the 64-chunks of the running sum straddle them
     free = orc.load_map("floor_plan")
     g = (free * 255).astype(np.uint8)
     rows, cols = g.shape
