@@ -140,3 +140,13 @@ def test_clearance_grid_brute_force(hh):
                         d = min(d, int(np.max(np.abs(occ - [i, j]), axis=1).min()))
                     exp = min(d, 255)
                 assert E[i, j] == exp
+
+
+def test_ray_functions_under_address_and_ub_sanitizers(hh):
+    """tests/host_harness/ray_san: the fast hit search and the exact jumps built with -fsanitize=address,undefined.
+    The padded clearance grid is an exactly sized heap buffer there, so a lookup outside its two-cell
+    frame (a GPU memory fault in the kernel) or an out-of-range double->int conversion aborts the run."""
+    exe = os.path.join(HERE, "host_harness", "ray_san")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "mismatches 0 advance_mismatches 0" in out.stdout
