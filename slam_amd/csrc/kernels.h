@@ -844,29 +844,27 @@ __global__ void __launch_bounds__(256) k_clone_maps(const uint8_t* maps, uint8_t
 }
 
 // ---- tiled canvases: table gather at resample, collection of unreferenced tiles, import / export ----
-// Resample (slam/mcl.cpp:147-155 without the deep copy): new table p = old table src[p].  A tile the
-// source owned stays owned by ONE of the slots that selected the source (the lowest, heir[src]); the
-// other slots see it as shared and get their copies from k_tile_copy before anybody writes.  With
-// `inherit` off (sensor range beyond what k_tile_plan covers, so a sibling might copy inside the
-// walk kernel while the heir writes) only a source selected exactly once passes ownership on.
-// Every referenced tile is marked with this collection's number (plain stores: no read-modify-write
-// on the hot tiles that thousands of tables share, and no clearing of the marks between collections).
-__global__ void __launch_bounds__(256) k_tile_mult(const int32_t* src, int64_t n, int* mult, int* heir)
+// Resample (slam/mcl.cpp:147-155 without the deep copy): new table p = old table src[p].  A tile stays
+// owned only if its source owned it and was selected exactly once (mult[src] == 1); any other
+// tile is shared or treated as shared (at worst one needless copy later).  (Letting one of several
+// children inherit the ownership is NOT valid: it would write in place a tile its siblings still
+// reference outside their own sensor range.)  Every referenced tile is marked with this
+// collection's number (plain stores: no read-modify-write on the hot tiles that thousands of tables
+// share, and no clearing of the marks between collections).
+__global__ void __launch_bounds__(256) k_tile_mult(const int32_t* src, int64_t n, int* mult)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    atomicAdd(&mult[src[k]], 1);
-    atomicMin(&heir[src[k]], (int)k);
+    if (k < n) atomicAdd(&mult[src[k]], 1);
 }
 
 __global__ void __launch_bounds__(256) k_tab_gather(const int32_t* tab, int32_t* tab2, const int32_t* src, int T,
-                                                    const int* mult, const int* heir, int inherit, int* ref, int live)
+                                                    const int* mult, int* ref, int live)
 {
     const size_t p = blockIdx.x;
     const int s = src[p];
     const int32_t* from = tab + (size_t)s * T;
     int32_t* to = tab2 + p * T;
-    const bool keep = mult[s] == 1 || (inherit && heir[s] == (int)p);
+    const bool keep = mult[s] == 1;
     for (int t = threadIdx.x; t < T; t += blockDim.x)
     {
         const int e = from[t];

@@ -89,7 +89,6 @@ struct slam_mcl
     int32_t *tile_wl_p = nullptr, *tile_wl_t = nullptr;  // work list of k_tile_plan / k_tile_copy
     int *tile_ref = nullptr, *tile_ctrl = nullptr;  // ctrl: cursor, free count, error flag
     uint8_t* tile_dense = nullptr;     // one dense canvas (import / export staging)
-    bool tile_inherit = false;  // the last planned range covered everything a walk can write
     int tile_gen = 0;  // number of the last collection: a tile is referenced iff its mark equals -tile_gen
     bool maps_pending = false;  // SLAM-mode shard: poses resampled, canvases not yet (shard_select done)
     // scan
@@ -341,7 +340,6 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             // (bounding square in tiles; capped: what it misses is copied inside the kernel)
             const int span = 2 * std::max(h->tile_T / h->tile_tc, h->tile_tc) + 1;
             const int side = std::min(std::min(2 * (int)std::ceil(std::fmin(range, 1.0e6) / 64.0) + 3, span), 31);
-            h->tile_inherit = 2 * (int)std::ceil(std::fmin(range, 1.0e6) / 64.0) + 3 <= side || side == span;
             const int64_t per = std::min<int64_t>((int64_t)side * side, h->tile_T);
             const int64_t blocks = std::min<int64_t>(h->n * per, h->tile_cap);
             slamk::TilePlan pl = {h->tile_wl_p, h->tile_wl_t};
@@ -564,15 +562,13 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
         // slam/mcl.cpp:147-155 without the deep copy: the selected particles share their source's
         // tiles until one of them writes
         slam_mcl::Span span(h, G_CLONE);
-        int* mult = reinterpret_cast<int*>(h->tile_wl_t);  // free between passes; holds 2 n entries
-        int* heir = mult + n;
+        int* mult = reinterpret_cast<int*>(h->tile_wl_t);  // free between passes; holds n entries
         HIPCHK(hipMemsetAsync(mult, 0, sizeof(int) * (size_t)n, h->stream));
-        HIPCHK(hipMemsetAsync(heir, 0x7f, sizeof(int) * (size_t)n, h->stream));
         HIPCHK(hipMemsetAsync(h->tile_ctrl, 0, 2 * sizeof(int), h->stream));
         ++h->tile_gen;
-        hipLaunchKernelGGL(slamk::k_tile_mult, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, h->src, n, mult, heir);
+        hipLaunchKernelGGL(slamk::k_tile_mult, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, h->src, n, mult);
         hipLaunchKernelGGL(slamk::k_tab_gather, dim3((unsigned)n), dim3(256), 0, h->stream, h->tile_tab, h->tile_tab2,
-                           h->src, h->tile_T, mult, heir, h->tile_inherit ? 1 : 0, h->tile_ref, -h->tile_gen);
+                           h->src, h->tile_T, mult, h->tile_ref, -h->tile_gen);
         std::swap(h->tile_tab, h->tile_tab2);
         hipLaunchKernelGGL(slamk::k_tile_free, dim3((unsigned)cdiv(h->tile_cap, 8192)), dim3(256), 0, h->stream, h->tile_ref,
                            -h->tile_gen, (int)h->tile_cap, h->tile_free, h->tile_ctrl);
@@ -753,7 +749,7 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
         TRY(dev_alloc(&h->tile_tab2, (size_t)n * h->tile_T));
         TRY(dev_alloc(&h->tile_free, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_wl_p, (size_t)h->tile_cap));
-        TRY(dev_alloc(&h->tile_wl_t, (size_t)std::max<int64_t>(h->tile_cap, 2 * n)));  // doubles as the multiplicity / heir arrays
+        TRY(dev_alloc(&h->tile_wl_t, (size_t)std::max<int64_t>(h->tile_cap, n)));  // doubles as the multiplicity array
         TRY(dev_alloc(&h->tile_ref, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_ctrl, 4));
         TRY(dev_alloc(&h->tile_dense, h->map_stride));

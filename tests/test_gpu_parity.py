@@ -388,6 +388,36 @@ def test_tiled_canvases_match_dense_and_oracle(sa):
     f.close()
 
 
+def test_tiled_canvases_reuse_collected_tiles(sa):
+    """A pool much smaller than the dense footprint, refilled by the collection at every resample:
+    twelve steps of a moving robot, every canvas equal to the dense handle's at every step."""
+    rng = np.random.default_rng(62)
+    N, B, rows, cols, zmax, seed = 512, 45, 640, 640, 150.0, 0x711F
+    free = orc.load_map("map")
+    T = ((rows + 63) // 64) * ((cols + 63) // 64)
+    dense = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed)
+    tiled = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed, map_storage=sa.capi.MAPS_TILED,
+                      tile_pool_tiles=int(0.75 * N * T))
+    x, y, th = cloud(rng, N, 200.0, 200.0, sxy=2.0, sth=0.1, th0=0.6)
+    for f in (dense, tiled):
+        f.set_poses(x, y, th)
+    pose = np.array([400.0, 400.0, np.pi / 90])
+    peak = 0
+    for step in range(12):
+        pose[:2] += 6.0 * np.array([np.cos(0.6), np.sin(0.6)])
+        ang, dist = orc.make_scan(free, pose, OFFSET, B, max_dist=zmax)
+        for f in (dense, tiled):
+            f.predict([0.0, 6.0, 0.0], ALPHAS)
+            f.update(ang, dist, 5.0, zmax, OFFSET)
+        assert np.array_equal(dense.last_indices(), tiled.last_indices())
+        assert_bits(tiled.weights(), dense.weights(), f"weights, step {step}")
+        for p in rng.choice(N, 6, replace=False):
+            assert np.array_equal(tiled.map_of(int(p)), dense.map_of(int(p))), f"canvas {p}, step {step}"
+        peak = max(peak, tiled.tile_stats()["live"])
+    assert 0 < peak < 0.75 * N * T
+    dense.close(), tiled.close()
+
+
 def test_tiled_pool_exhaustion_is_reported(sa):
     N, B, rows, cols = 32, 90, 400, 400
     free = orc.load_map("map")
