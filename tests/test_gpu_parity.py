@@ -160,6 +160,47 @@ def test_weights_localization(sa, raycaster, mapname, N, B, zmax, stddev):
     f.close()
 
 
+@pytest.mark.parametrize("N", [4097, 333])     # particle lanes with a ragged last block / beam lanes
+@pytest.mark.parametrize("mapname,zmax", [("floor_plan", 500.0), ("floor_plan", 3.2), ("tiny", 40.0), ("tiny", 0.6)])
+def test_weights_hostile_poses(sa, N, mapname, zmax):
+    """Particles far outside the grid, at int-overflowing and 2^53-sized coordinates, on cell corners and
+    with huge headings; a 5x7 map; ranges below one cell.  Hit cells, positions and weights equal
+    the oracle's bit for bit in every kernel shape (the order keys and the exact-jump set-up must
+    cope with all of it)."""
+    rng = np.random.default_rng(zlib.crc32(f"hostile-{N}-{mapname}-{zmax}".encode()))
+    if mapname == "tiny":
+        g = np.full((5, 7), 255, np.uint8)
+        g[2, 4] = 0
+    else:
+        g = (orc.load_map(mapname) * 255).astype(np.uint8)
+    rows, cols = g.shape
+    B = 24
+    ang = np.linspace(-np.pi, np.pi, B, endpoint=False)
+    dist = rng.uniform(0.0, zmax, B)
+    dist[::5] = zmax
+    x = rng.uniform(-5, cols + 5, N)
+    y = rng.uniform(-5, rows + 5, N)
+    th = rng.uniform(-7, 7, N)
+    k = N // 8
+    x[:k] = rng.choice([-1e6, 3e9, -5e9, 1e15, 9.1e15, 2.0 ** 31, -(2.0 ** 31) - 1], k)
+    y[k:2 * k] = rng.choice([-1e6, 3e9, -5e9, 1e15, 2.0 ** 52, 0.0, -0.0], k)
+    x[2 * k:3 * k] = np.floor(x[2 * k:3 * k])
+    y[2 * k:3 * k] = np.floor(y[2 * k:3 * k])
+    th[3 * k:4 * k] = rng.choice([1e5, -1e5, 1e300, 0.0, np.pi / 2, -np.pi], k)
+    ow, oxy, ocell, _ = orc.update_weights(x, y, th, g, ang, dist, 2.0, zmax, [0.5, 1.5, 0.1], want_hits=True, math=orc.DET)
+    for shape in ("fast", "beam_lanes", "particle_lanes", "walk"):
+        f = sa.Filter(N, rows, cols, raycaster=RAYCASTERS[shape])
+        f.set_map(g)
+        f.set_poses(x, y, th)
+        f.record_hits(True)
+        f.update_weights(ang, dist, 2.0, zmax, [0.5, 1.5, 0.1])
+        hxy, hcell = f.hits()
+        assert np.array_equal(hcell, ocell), f"{shape}: {np.sum(hcell != ocell)} hit cells differ"
+        assert_bits(hxy, oxy, f"{shape}: hit positions")
+        assert_bits(f.weights(), ow, f"{shape}: weights")
+        f.close()
+
+
 def test_weights_degenerate_underflow_and_tiny_ranges(sa):
     rng = np.random.default_rng(5)
     g = grid_of("floor_plan")
