@@ -227,7 +227,7 @@ def test_weights_degenerate_underflow_and_tiny_ranges(sa):
 
 
 # ---- K2b SLAM mode: raycast + likelihood + occupancy update ---------------------------------------
-@pytest.mark.parametrize("shape", ["wave", "thread"])
+@pytest.mark.parametrize("shape", ["wave", "thread", "tiled"])
 @pytest.mark.parametrize("B,zmax", [(90, 500.0), (130, 61.5)])
 def test_weights_slam_mode_maps_bit_exact(sa, shape, B, zmax):
     rng = np.random.default_rng(21)
@@ -235,9 +235,11 @@ def test_weights_slam_mode_maps_bit_exact(sa, shape, B, zmax):
     free = orc.load_map("map")
     ang, dist = orc.make_scan(free, [400.0, 400.0, np.pi / 90], OFFSET, B, max_dist=zmax)
     f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM,
-                  raycaster=sa.capi.RAYCAST_FAST_BEAM_LANES if shape == "wave" else sa.capi.RAYCAST_FAST_PARTICLE_LANES)
+                  raycaster=sa.capi.RAYCAST_FAST_PARTICLE_LANES if shape == "thread" else sa.capi.RAYCAST_FAST_BEAM_LANES,
+                  map_storage=sa.capi.MAPS_TILED if shape == "tiled" else sa.capi.MAPS_DENSE)
     x, y, th = cloud(rng, N, cols / 2, rows / 2, sxy=6.0, sth=0.3, th0=np.pi / 2)
     x[:3], y[:3] = [2.5, cols - 1.5, -20.0], [rows - 2.5, 1.5, 100.0]   # at the canvas border / outside
+    x[3:6], y[3:6] = [3e9, -1e15, 150.0], [10.0, 20.0, -(2.0 ** 40)]   # far outside, beyond int range
     f.set_poses(x, y, th)
     maps = np.full((N, rows, cols), 128, np.uint8)
     f.record_hits(True)
