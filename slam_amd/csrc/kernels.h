@@ -366,6 +366,14 @@ __device__ __forceinline__ uint64_t lanes_upto(int l) { return l >= 63 ? ~0ull :
 // not kept while the kernel runs: the resample step rebuilds them from the tables (k_tile_*).
 enum { TILE_SHIFT = 6, TILE_MASK = 63, TILE_BYTES = 4096, TILE_OWN = 0x40000000 };
 
+// Cells inside a tile are stored as 8x8 micro-blocks of 64 contiguous bytes: one memory sector then
+// holds an 8x8 patch of the canvas and a ray crosses about one sector per 8 cells whatever its
+// direction (row-major rows would give a steep ray a new sector for every cell).
+__device__ __forceinline__ int tile_cell(int i, int j)
+{
+    return (((i & TILE_MASK) >> 3) << 9) | (((j & TILE_MASK) >> 3) << 6) | ((i & 7) << 3) | (j & 7);
+}
+
 struct DenseMap
 {
     uint8_t* base;
@@ -399,7 +407,7 @@ struct TiledMap
     __device__ __forceinline__ uint8_t load(int i, int j) const
     {
         const int id = ltab[(i >> TILE_SHIFT) * tcols + (j >> TILE_SHIFT)] & ~TILE_OWN;
-        return pool[(size_t)id * TILE_BYTES + (size_t)(((i & TILE_MASK) << TILE_SHIFT) | (j & TILE_MASK))];
+        return pool[(size_t)id * TILE_BYTES + (size_t)tile_cell(i, j)];
     }
     __device__ __forceinline__ void store(bool wr, int i, int j, uint8_t v, int lane)
     {
@@ -453,7 +461,7 @@ struct TiledMap
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         if (wr)
-            pool[(size_t)(e & ~TILE_OWN) * TILE_BYTES + (size_t)(((i & TILE_MASK) << TILE_SHIFT) | (j & TILE_MASK))] = v;
+            pool[(size_t)(e & ~TILE_OWN) * TILE_BYTES + (size_t)tile_cell(i, j)] = v;
     }
 };
 
@@ -1022,7 +1030,7 @@ __global__ void __launch_bounds__(256) k_untile(const uint8_t* pool, const int32
     if (k >= (int64_t)rows * cols) return;
     const int i = (int)(k / cols), j = (int)(k - (int64_t)i * cols);
     const int id = tab_p[(i >> TILE_SHIFT) * tcols + (j >> TILE_SHIFT)] & ~TILE_OWN;
-    out[k] = pool[(size_t)id * TILE_BYTES + (size_t)(((i & TILE_MASK) << TILE_SHIFT) | (j & TILE_MASK))];
+    out[k] = pool[(size_t)id * TILE_BYTES + (size_t)tile_cell(i, j)];
 }
 
 // one block per tile of ONE particle: a fresh owned tile filled from the dense canvas (128 beyond its edges)
@@ -1045,7 +1053,7 @@ __global__ void __launch_bounds__(256) k_tile_import(const uint8_t* dense, int r
     for (int q = threadIdx.x; q < TILE_BYTES; q += blockDim.x)
     {
         const int i = (ti << TILE_SHIFT) + (q >> TILE_SHIFT), j = (tj << TILE_SHIFT) + (q & TILE_MASK);
-        to[q] = (i < rows && j < cols) ? dense[(size_t)i * cols + j] : (uint8_t)128;
+        to[tile_cell(i, j)] = (i < rows && j < cols) ? dense[(size_t)i * cols + j] : (uint8_t)128;
     }
     if (threadIdx.x == 0) tab_p[t] = nid | TILE_OWN;
 }
