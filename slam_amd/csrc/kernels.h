@@ -852,56 +852,49 @@ __global__ void __launch_bounds__(256) k_clone_maps(const uint8_t* maps, uint8_t
 }
 
 // ---- tiled canvases: table gather at resample, collection of unreferenced tiles, import / export ----
-// Resample (slam/mcl.cpp:147-155 without the deep copy): new table p = old table src[p].  A tile stays
-// owned only if its source owned it and was selected exactly once (mult[src] == 1); any other
-// tile is shared or treated as shared (at worst one needless copy later).  (Letting one of several
-// children inherit the ownership is NOT valid: it would write in place a tile its siblings still
-// reference outside their own sensor range.)  Every referenced tile is marked with this
-// collection's number (plain stores: no read-modify-write on the hot tiles that thousands of tables
-// share, and no clearing of the marks between collections).
-__global__ void __launch_bounds__(256) k_tile_mult(const int32_t* src, int64_t n, int* mult)
-{
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) atomicAdd(&mult[src[k]], 1);
-}
-
-__global__ void __launch_bounds__(256) k_tab_gather(const int32_t* tab, int32_t* tab2, const int32_t* src, int T,
-                                                    const int* mult, int* ref, int live)
+// Resample (slam/mcl.cpp:147-155 without the deep copy): new table p = old table src[p]
+// (k_tab_gather; src == nullptr keeps the tables), then an exact, atomic-free census of the tiles:
+//   k_tab_gather   every entry stamps its tile with the collection's number (`live`) and with its own
+//                  entry index (who[id]; whichever entry wins the race)
+//   k_tile_shared  every entry that did not win stamps the tile as shared
+//   k_tile_own     an entry owns its tile iff it won and nobody stamped the tile shared
+// Plain racing stores only: a reference COUNT needs read-modify-writes on the few hot tiles that
+// thousands of tables share (1.6 ms in the first version), and a rule of thumb (ownership survives
+// only in a sole child) leaves exclusive tiles unowned, which costs copies and pool space.
+// (Letting one of several children inherit the ownership is NOT valid: it would write in place a
+// tile its siblings still reference outside their own sensor range.)
+__global__ void __launch_bounds__(256) k_tab_gather(const int32_t* tab, int32_t* tab2, const int32_t* src, int T, int* ref,
+                                                    int* who, int live)
 {
     const size_t p = blockIdx.x;
-    const int s = src[p];
-    const int32_t* from = tab + (size_t)s * T;
+    const int32_t* from = tab + (size_t)(src ? src[p] : (int32_t)p) * T;
     int32_t* to = tab2 + p * T;
-    const bool keep = mult[s] == 1;
     for (int t = threadIdx.x; t < T; t += blockDim.x)
     {
-        const int e = from[t];
-        const int id = e & ~TILE_OWN;
-        to[t] = keep ? e : id;
-        if (id) ref[id] = live;
+        const int id = from[t] & ~TILE_OWN;
+        to[t] = id;
+        if (id)
+        {
+            ref[id] = live;
+            who[id] = (int)(p * T + t);
+        }
     }
 }
 
-__global__ void __launch_bounds__(256) k_tile_count(const int32_t* tab, int64_t total, int* ref)
+__global__ void __launch_bounds__(256) k_tile_shared(const int32_t* tab, int64_t total, const int* who, int* shared, int live)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total) return;
-    const int id = tab[k] & ~TILE_OWN;
-    if (id) atomicAdd(&ref[id], 1);
+    const int id = tab[k];
+    if (id && who[id] != (int)k) shared[id] = live;
 }
 
-// (general collection, after k_tile_count) own what is referenced once.  The counts double as marks
-// for k_tile_free: a referenced tile's count is replaced by `live` (negative: never a count).
-__global__ void __launch_bounds__(256) k_tile_own(int32_t* tab, int64_t total, int* ref, int live)
+__global__ void __launch_bounds__(256) k_tile_own(int32_t* tab, int64_t total, const int* who, const int* shared, int live)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total) return;
-    const int id = tab[k] & ~TILE_OWN;
-    if (!id) return;
-    const int c = ref[id];
-    // c is a count (1 = exclusive) or already `live` (another entry of a shared tile got here first)
-    tab[k] = (c == 1) ? (id | TILE_OWN) : id;
-    if (c != live) ref[id] = live;
+    const int id = tab[k];
+    if (id && who[id] == (int)k && shared[id] != live) tab[k] = id | TILE_OWN;
 }
 
 // free list = every tile but the blank one whose mark is not `live` (order irrelevant).  8192 ids per

@@ -87,9 +87,10 @@ struct slam_mcl
     uint8_t* tile_pool = nullptr;
     int32_t *tile_tab = nullptr, *tile_tab2 = nullptr, *tile_free = nullptr;
     int32_t *tile_wl_p = nullptr, *tile_wl_t = nullptr;  // work list of k_tile_plan / k_tile_copy
-    int *tile_ref = nullptr, *tile_ctrl = nullptr;  // ctrl: cursor, free count, error flag
+    int *tile_ref = nullptr, *tile_who = nullptr, *tile_shared = nullptr;  // per tile: live mark, winning entry, shared mark
+    int* tile_ctrl = nullptr;                                              // cursor, free count, error flag, cursor before the plan
     uint8_t* tile_dense = nullptr;     // one dense canvas (import / export staging)
-    int tile_gen = 0;  // number of the last collection: a tile is referenced iff its mark equals -tile_gen
+    int tile_gen = 0;  // number of the last collection: a tile is referenced iff its mark equals it
     bool maps_pending = false;  // SLAM-mode shard: poses resampled, canvases not yet (shard_select done)
     // scan
     int Bcap = 0;
@@ -177,20 +178,22 @@ int finish(slam_mcl* h)
     return SLAM_OK;
 }
 
-// SLAM_MAPS_TILED: rebuild the reference counts from the tables, mark exclusively held tiles as
-// owned, list the unreferenced ones as free and restart the allocation cursor.
-int tile_collect(slam_mcl* h)
+// SLAM_MAPS_TILED: new tables (src != nullptr: table p = old table src[p]), census of the tiles (who
+// owns what, exactly), free list of the unreferenced ones, allocation cursor restarted.
+int tile_collect(slam_mcl* h, const int32_t* src)
 {
     const int64_t total = (int64_t)h->n * h->tile_T;
-    HIPCHK(hipMemsetAsync(h->tile_ref, 0, sizeof(int) * (size_t)h->tile_cap, h->stream));
+    const int live = ++h->tile_gen;  // marks are never cleared: a tile is referenced iff its mark is this number
     HIPCHK(hipMemsetAsync(h->tile_ctrl, 0, 2 * sizeof(int), h->stream));  // cursor and count; the error flag stays
-    HIPCHK(hipMemsetAsync(h->tile_wl_p, 0xff, sizeof(int32_t) * (size_t)h->tile_cap, h->stream));
-    hipLaunchKernelGGL(slamk::k_tile_count, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, total,
-                       h->tile_ref);
+    hipLaunchKernelGGL(slamk::k_tab_gather, dim3((unsigned)h->n), dim3(256), 0, h->stream, h->tile_tab, h->tile_tab2, src,
+                       h->tile_T, h->tile_ref, h->tile_who, live);
+    std::swap(h->tile_tab, h->tile_tab2);
+    hipLaunchKernelGGL(slamk::k_tile_shared, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, total,
+                       h->tile_who, h->tile_shared, live);
     hipLaunchKernelGGL(slamk::k_tile_own, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, total,
-                       h->tile_ref, -(++h->tile_gen));
+                       h->tile_who, h->tile_shared, live);
     hipLaunchKernelGGL(slamk::k_tile_free, dim3((unsigned)cdiv(h->tile_cap, 8192)), dim3(256), 0, h->stream, h->tile_ref,
-                       -h->tile_gen, (int)h->tile_cap, h->tile_free, h->tile_ctrl);
+                       live, (int)h->tile_cap, h->tile_free, h->tile_ctrl);
     HIPCHK(hipGetLastError());
     return SLAM_OK;
 }
@@ -562,17 +565,8 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
         // slam/mcl.cpp:147-155 without the deep copy: the selected particles share their source's
         // tiles until one of them writes
         slam_mcl::Span span(h, G_CLONE);
-        int* mult = reinterpret_cast<int*>(h->tile_wl_t);  // free between passes; holds n entries
-        HIPCHK(hipMemsetAsync(mult, 0, sizeof(int) * (size_t)n, h->stream));
-        HIPCHK(hipMemsetAsync(h->tile_ctrl, 0, 2 * sizeof(int), h->stream));
-        ++h->tile_gen;
-        hipLaunchKernelGGL(slamk::k_tile_mult, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, h->src, n, mult);
-        hipLaunchKernelGGL(slamk::k_tab_gather, dim3((unsigned)n), dim3(256), 0, h->stream, h->tile_tab, h->tile_tab2,
-                           h->src, h->tile_T, mult, h->tile_ref, -h->tile_gen);
-        std::swap(h->tile_tab, h->tile_tab2);
-        hipLaunchKernelGGL(slamk::k_tile_free, dim3((unsigned)cdiv(h->tile_cap, 8192)), dim3(256), 0, h->stream, h->tile_ref,
-                           -h->tile_gen, (int)h->tile_cap, h->tile_free, h->tile_ctrl);
-        HIPCHK(hipGetLastError());
+        int rc = tile_collect(h, h->src);
+        if (rc) return rc;
     }
     else if (h->prm.mode == SLAM_MODE_SLAM && clone_local)
     {
@@ -611,7 +605,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
                     h->inj_normals, h->inj_uniforms, h->idx, h->perm, h->slots, h->src,   h->keys, h->keys2,
                     h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
                     h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->wlin, h->wmax,
-                    h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_ctrl, h->tile_dense,
+                    h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_who, h->tile_shared, h->tile_ctrl, h->tile_dense,
                     h->tile_wl_p, h->tile_wl_t};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -742,15 +736,17 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
         h->tile_T = ((h->rows + 63) / 64) * h->tile_tc;
         const int64_t dflt = (3 * n * h->tile_T + 1) / 2 + 1;
         h->tile_cap = h->prm.tile_pool_tiles > 0 ? h->prm.tile_pool_tiles + 1 : dflt;  // + the blank tile 0
-        if (h->tile_cap >= (int64_t)slamk::TILE_OWN || n != h->n_glob)
-            rc = fail(SLAM_ERR_ARG, "tiled canvases: pool too large, or a shard (not supported yet)");
+        if (h->tile_cap >= (int64_t)slamk::TILE_OWN || n * h->tile_T >= 2147483647LL || n != h->n_glob)
+            rc = fail(SLAM_ERR_ARG, "tiled canvases: pool or tables too large, or a shard (not supported yet)");
         TRY(dev_alloc(&h->tile_pool, (size_t)h->tile_cap * slamk::TILE_BYTES));
         TRY(dev_alloc(&h->tile_tab, (size_t)n * h->tile_T));
         TRY(dev_alloc(&h->tile_tab2, (size_t)n * h->tile_T));
         TRY(dev_alloc(&h->tile_free, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_wl_p, (size_t)h->tile_cap));
-        TRY(dev_alloc(&h->tile_wl_t, (size_t)std::max<int64_t>(h->tile_cap, n)));  // doubles as the multiplicity array
+        TRY(dev_alloc(&h->tile_wl_t, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_ref, (size_t)h->tile_cap));
+        TRY(dev_alloc(&h->tile_who, (size_t)h->tile_cap));
+        TRY(dev_alloc(&h->tile_shared, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_ctrl, 4));
         TRY(dev_alloc(&h->tile_dense, h->map_stride));
         if (!rc)
@@ -758,9 +754,13 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
             // slam/mcl.cpp:30: every canvas is the blank tile 0 (128), nothing else is referenced
             bool ok = hipMemsetAsync(h->tile_pool, 128, slamk::TILE_BYTES, h->stream) == hipSuccess &&
                       hipMemsetAsync(h->tile_tab, 0, sizeof(int32_t) * (size_t)n * h->tile_T, h->stream) == hipSuccess &&
-                      hipMemsetAsync(h->tile_ctrl, 0, 4 * sizeof(int), h->stream) == hipSuccess;
+                      hipMemsetAsync(h->tile_ctrl, 0, 4 * sizeof(int), h->stream) == hipSuccess &&
+                      hipMemsetAsync(h->tile_ref, 0, sizeof(int) * (size_t)h->tile_cap, h->stream) == hipSuccess &&
+                      hipMemsetAsync(h->tile_who, 0, sizeof(int) * (size_t)h->tile_cap, h->stream) == hipSuccess &&
+                      hipMemsetAsync(h->tile_shared, 0, sizeof(int) * (size_t)h->tile_cap, h->stream) == hipSuccess &&
+                      hipMemsetAsync(h->tile_wl_p, 0xff, sizeof(int32_t) * (size_t)h->tile_cap, h->stream) == hipSuccess;
             if (!ok) rc = fail(SLAM_ERR_HIP, "tile pool initialisation");
-            TRY(tile_collect(h));
+            TRY(tile_collect(h, nullptr));
         }
     }
     else if (!rc && h->prm.mode == SLAM_MODE_SLAM)
@@ -879,7 +879,7 @@ SLAM_API int slam_mcl_set_maps_u8(slam_mcl* h, const uint8_t* maps, int64_t firs
     {
         // drop the old tiles of these particles, then import every canvas as fresh owned tiles
         HIPCHK(hipMemsetAsync(h->tile_tab + (size_t)first * h->tile_T, 0, sizeof(int32_t) * (size_t)count * h->tile_T, h->stream));
-        if ((rc = tile_collect(h))) return rc;
+        if ((rc = tile_collect(h, nullptr))) return rc;
         for (int64_t k = 0; k < count; ++k)
         {
             HIPCHK(hipMemcpyAsync(h->tile_dense, maps + bytes * (size_t)k, bytes, hipMemcpyHostToDevice, h->stream));
