@@ -26,8 +26,11 @@ CR = int(os.environ.get("SB_ROWS", C))
 variants = [("wave", capi.RAYCAST_FAST_BEAM_LANES, capi.MAPS_DENSE), ("tiled", capi.RAYCAST_FAST, capi.MAPS_TILED)]
 if os.environ.get("SB_THREAD", "0") == "1":
     variants.append(("thread", capi.RAYCAST_FAST_PARTICLE_LANES, capi.MAPS_DENSE))
+if os.environ.get("SB_ONLY"):
+    variants = [v for v in variants if v[0] == os.environ["SB_ONLY"]]
 for name, rc, storage in variants:
-    f = sa.Filter(N, CR, C, mode=capi.MODE_SLAM, raycaster=rc, map_storage=storage)
+    f = sa.Filter(N, CR, C, mode=capi.MODE_SLAM, raycaster=rc, map_storage=storage,
+                  tile_pool_tiles=int(os.environ.get("SB_POOL", 0)) if storage == capi.MAPS_TILED else 0)
     f.profile(True)
     for k in range(len(scans)):
         f.predict(odom, alphas)
