@@ -38,7 +38,7 @@ enum { SLAM_PREFIX_BLOCKED = 0, SLAM_PREFIX_REFERENCE = 1 };
 enum { SLAM_RESAMPLE_MULTINOMIAL = 0, SLAM_RESAMPLE_SYSTEMATIC = 1 };
 enum { SLAM_SORT_FULL = 0, SLAM_SORT_NONE = 1 };
 enum { SLAM_WEIGHT_LINEAR = 0, SLAM_WEIGHT_LOG = 1 };
-enum { SLAM_MAPS_DENSE = 0, SLAM_MAPS_TILED = 1 };
+enum { SLAM_MAPS_AUTO = 0, SLAM_MAPS_DENSE = 1, SLAM_MAPS_TILED = 2 };
 enum
 {
     SLAM_RAYCAST_FAST = 0,                /* clearance-skipping search; kernel shape chosen by N */
@@ -79,11 +79,13 @@ typedef struct slam_mcl_params
                               SLAM_WEIGHT_LOG (opt-in, no reference counterpart): the weight column
                               holds sum_b log w_b and the selection of slam/mcl.cpp:157-203 runs on
                               exp(lw - max lw), max over the whole filter (all shards) */
-    int32_t map_storage;   /* SLAM mode.  SLAM_MAPS_DENSE: every particle holds rows*cols bytes and the
-                              resample deep-copies them (slam/mcl.cpp:147-155).  SLAM_MAPS_TILED (opt-in,
-                              same results): canvases are tables of 64x64 copy-on-write tiles in a
-                              shared pool; the resample copies tables, a tile is copied when a
-                              particle that shares it first writes to it */
+    int32_t map_storage;   /* SLAM mode; the results do not depend on it.  SLAM_MAPS_DENSE: every particle
+                              holds rows*cols bytes and the resample deep-copies them, as
+                              slam/mcl.cpp:147-155 does.  SLAM_MAPS_TILED: canvases are tables of 64x64
+                              copy-on-write tiles in a shared pool; the resample copies tables, a tile
+                              is copied when a particle that shares it is about to write it
+                              (SURVEY.md §8f row 3).  SLAM_MAPS_AUTO (0): tiled, except for shards and
+                              for n_particles >= 262144 (not built on tiles yet): dense */
     int32_t reserved;
     int64_t tile_pool_tiles; /* SLAM_MAPS_TILED: tiles (4 KiB each) in the pool; 0 = 1.5 x particles x
                                 tiles per canvas, which can never run out */

@@ -14,7 +14,7 @@ PREFIX_BLOCKED, PREFIX_REFERENCE = 0, 1
 RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
 SORT_FULL, SORT_NONE = 0, 1
 WEIGHT_LINEAR, WEIGHT_LOG = 0, 1
-MAPS_DENSE, MAPS_TILED = 0, 1
+MAPS_AUTO, MAPS_DENSE, MAPS_TILED = 0, 1, 2
 RAYCAST_FAST, RAYCAST_WALK, RAYCAST_FAST_BEAM_LANES, RAYCAST_FAST_PARTICLE_LANES = 0, 1, 2, 3
 
 

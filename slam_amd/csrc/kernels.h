@@ -937,9 +937,14 @@ struct TilePlan
     int32_t *wl_p, *wl_t;  // work list, indexed like the free list: particle and tile slot (wl_p < 0: nothing to do)
 };
 
+// `sector_r[k]`, k = 0..255: how far the scan can write in the directions of sector k of the scan frame
+// (max over its beams of min(z, zmax) + 2, dilated by one sector): a tile farther away than that in
+// all the sectors it spans is not copied (a wall at 100 cells stops the writes there although the
+// sensor's range is 500).  Approximate on purpose (float, margins): a miss only moves the copy
+// into the walk kernel.
 __global__ void __launch_bounds__(256) k_tile_plan(int64_t n, const double* x, const double* y, const double* th, double sd,
-                                                   double stheta, double range, int rows, int cols, int side, TileArgs ta,
-                                                   TilePlan pl)
+                                                   double stheta, double srot, double range, const float* sector_r, int rows,
+                                                   int cols, int side, TileArgs ta, TilePlan pl)
 {
     __shared__ int cnt_s, base_s;
     const int64_t p = blockIdx.x;
@@ -964,7 +969,20 @@ __global__ void __launch_bounds__(256) k_tile_plan(int64_t n, const double* x, c
             const double r0 = (double)(ti << TILE_SHIFT), c0 = (double)(tj << TILE_SHIFT);
             const double dr = sr < r0 ? r0 - sr : (sr > r0 + 64.0 ? sr - (r0 + 64.0) : 0.0);
             const double dc = sc < c0 ? c0 - sc : (sc > c0 + 64.0 ? sc - (c0 + 64.0) : 0.0);
-            need = dr * dr + dc * dc <= range * range && !(tab_p[ti * ta.tcols + tj] & TILE_OWN);
+            const double dmin2 = dr * dr + dc * dc;
+            need = dmin2 <= range * range && !(tab_p[ti * ta.tcols + tj] & TILE_OWN);
+            const float dxw = (float)(c0 + 32.0 - sc), dyw = (float)(sr - (r0 + 32.0));  // to the tile's centre, y up
+            const float dcen = sqrtf(dxw * dxw + dyw * dyw);
+            if (need && dcen > 100.0f)
+            {
+                const float inv = 40.743665f;  // 256 / (2 pi)
+                const float alpha = atan2f(dyw, dxw) - (float)(th[p] + srot);
+                const float half = asinf(46.0f / dcen) * inv + 1.5f;  // half-diagonal of a tile, plus margin, in sectors
+                const int k0 = (int)floorf(alpha * inv - half), k1 = (int)floorf(alpha * inv + half);
+                float rmax = 0.0f;
+                for (int k = k0; k <= k1; ++k) rmax = fmaxf(rmax, sector_r[(k + 128) & 255]);
+                need = dmin2 <= (double)rmax * (double)rmax;
+            }
         }
         if (need && nmine < 4)
         {

@@ -90,6 +90,7 @@ struct slam_mcl
     int *tile_ref = nullptr, *tile_who = nullptr, *tile_shared = nullptr;  // per tile: live mark, winning entry, shared mark
     int* tile_ctrl = nullptr;                                              // cursor, free count, error flag, cursor before the plan
     uint8_t* tile_dense = nullptr;     // one dense canvas (import / export staging)
+    float* tile_sector = nullptr;      // 256 sectors of the scan frame: how far the current scan can write
     int tile_gen = 0;  // number of the last collection: a tile is referenced iff its mark equals it
     bool maps_pending = false;  // SLAM-mode shard: poses resampled, canvases not yet (shard_select done)
     // scan
@@ -346,9 +347,26 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             const int64_t per = std::min<int64_t>((int64_t)side * side, h->tile_T);
             const int64_t blocks = std::min<int64_t>(h->n * per, h->tile_cap);
             slamk::TilePlan pl = {h->tile_wl_p, h->tile_wl_t};
+            {
+                // per sector of the scan frame (sector k covers angles [-pi + k 2pi/256, ...)): the farthest write
+                float sec[256] = {0.0f}, dil[256];
+                const double* ang = h->scan_cache.data();
+                const double* zz = ang + 2 * (size_t)B;
+                for (int b = 0; b < B; ++b)
+                {
+                    double al = std::fmod(ang[b], 2 * M_PI);
+                    if (al >= M_PI) al -= 2 * M_PI;
+                    if (al < -M_PI) al += 2 * M_PI;
+                    const int k = (int)std::floor((al + M_PI) * (256.0 / (2 * M_PI))) & 255;
+                    const float r = (float)(std::fmin(zz[b], a.zmax) + 2.0) * 1.0001f;
+                    if (r > sec[k]) sec[k] = r;
+                }
+                for (int k = 0; k < 256; ++k) dil[k] = std::max(sec[k], std::max(sec[(k + 1) & 255], sec[(k + 255) & 255]));
+                HIPCHK(hipMemcpyAsync(h->tile_sector, dil, sizeof(dil), hipMemcpyHostToDevice, h->stream));
+            }
             hipLaunchKernelGGL(slamk::k_tile_mark, dim3(1), dim3(1), 0, h->stream, h->tile_ctrl);
             hipLaunchKernelGGL(slamk::k_tile_plan, dim3((unsigned)h->n), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th, a.sd,
-                               a.stheta, range, h->rows, h->cols, side, ta, pl);
+                               a.stheta, a.srot, range, h->tile_sector, h->rows, h->cols, side, ta, pl);
             hipLaunchKernelGGL(slamk::k_tile_copy, dim3((unsigned)blocks), dim3(256), 0, h->stream, ta, pl);
             size_t lds = 0;
             if ((size_t)h->tile_T * 16 <= 48 * 1024)
@@ -605,7 +623,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
                     h->inj_normals, h->inj_uniforms, h->idx, h->perm, h->slots, h->src,   h->keys, h->keys2,
                     h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
                     h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->wlin, h->wmax,
-                    h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_who, h->tile_shared, h->tile_ctrl, h->tile_dense,
+                    h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_who, h->tile_shared, h->tile_ctrl, h->tile_dense, h->tile_sector,
                     h->tile_wl_p, h->tile_wl_t};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -726,8 +744,10 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
         build_luts(t);
         if (hipMemcpy(h->luts, t, 512, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SLAM_ERR_HIP, "lut upload");
     }
-    if (!rc && h->prm.map_storage != SLAM_MAPS_DENSE && h->prm.map_storage != SLAM_MAPS_TILED)
-        rc = fail(SLAM_ERR_ARG, "map_storage must be SLAM_MAPS_DENSE or SLAM_MAPS_TILED");
+    if (!rc && (h->prm.map_storage < SLAM_MAPS_AUTO || h->prm.map_storage > SLAM_MAPS_TILED))
+        rc = fail(SLAM_ERR_ARG, "map_storage must be SLAM_MAPS_AUTO, SLAM_MAPS_DENSE or SLAM_MAPS_TILED");
+    if (!rc && h->prm.map_storage == SLAM_MAPS_AUTO)
+        h->prm.map_storage = (n == h->n_glob && n < 262144) ? SLAM_MAPS_TILED : SLAM_MAPS_DENSE;
     if (!rc && h->prm.mode == SLAM_MODE_SLAM && h->prm.map_storage == SLAM_MAPS_TILED)
     {
         h->tiled = true;
@@ -749,6 +769,7 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
         TRY(dev_alloc(&h->tile_shared, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_ctrl, 4));
         TRY(dev_alloc(&h->tile_dense, h->map_stride));
+        TRY(dev_alloc(&h->tile_sector, 256));
         if (!rc)
         {
             // slam/mcl.cpp:30: every canvas is the blank tile 0 (128), nothing else is referenced

@@ -21,6 +21,8 @@ class HipShard:
     """Shard backend on one MI355X through the C ABI."""
 
     def __init__(self, n_local, rows, cols, rank, world, device, seed, stream=None, mode=capi.MODE_LOCALIZATION, **kw):
+        if mode == capi.MODE_SLAM:
+            kw.setdefault("map_storage", capi.MAPS_DENSE)  # whole canvases travel between ranks (tiles do not yet)
         self.f = Filter(n_local, rows, cols, mode=mode, device=device, seed=seed,
                         sort=capi.SORT_NONE, prefix_order=capi.PREFIX_BLOCKED, global_first=rank * n_local,
                         global_n=world * n_local, stream=stream, **kw)

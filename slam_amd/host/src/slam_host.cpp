@@ -40,9 +40,9 @@ MCL::MCL(int n_particles, const cv::Size& canvas_size) : m_canvas_size(canvas_si
     p.seed = std::getenv("SLAM_SEED") ? std::strtoull(std::getenv("SLAM_SEED"), nullptr, 0)
                                       : static_cast<uint64_t>(std::chrono::system_clock::now().time_since_epoch().count());
     p.sort = SLAM_SORT_FULL;
-    // same results either way; SLAM_MAPS=tiled holds the canvases as copy-on-write tiles
+    // same results either way: copy-on-write tiles by default, SLAM_MAPS=dense|tiled forces one
     const char* maps = std::getenv("SLAM_MAPS");
-    p.map_storage = (maps && std::string(maps) == "tiled") ? SLAM_MAPS_TILED : SLAM_MAPS_DENSE;
+    p.map_storage = !maps ? SLAM_MAPS_AUTO : (std::string(maps) == "tiled" ? SLAM_MAPS_TILED : SLAM_MAPS_DENSE);
     check(slam_mcl_create(&p, &m_handle), "slam_mcl_create");
 }
 

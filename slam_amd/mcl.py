@@ -35,7 +35,7 @@ class Filter:
     def __init__(self, n_particles, rows, cols, mode=capi.MODE_LOCALIZATION, device=0, seed=0x5EED0001,
                  noise=capi.NOISE_PHILOX, prefix_order=capi.PREFIX_BLOCKED, resampler=capi.RESAMPLE_MULTINOMIAL,
                  sort=capi.SORT_FULL, raycaster=capi.RAYCAST_FAST, global_first=0, global_n=0, stream=None,
-                 async_launch=False, weight_domain=capi.WEIGHT_LINEAR, map_storage=capi.MAPS_DENSE, tile_pool_tiles=0):
+                 async_launch=False, weight_domain=capi.WEIGHT_LINEAR, map_storage=capi.MAPS_AUTO, tile_pool_tiles=0):
         self.lib = capi.load_library()
         p = capi.Params()
         p.struct_size = ctypes.sizeof(capi.Params)

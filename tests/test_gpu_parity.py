@@ -438,7 +438,7 @@ def test_tiled_canvases_reuse_collected_tiles(sa):
     N, B, rows, cols, zmax, seed = 512, 45, 640, 640, 150.0, 0x711F
     free = orc.load_map("map")
     T = ((rows + 63) // 64) * ((cols + 63) // 64)
-    dense = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed)
+    dense = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed, map_storage=sa.capi.MAPS_DENSE)
     tiled = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed, map_storage=sa.capi.MAPS_TILED,
                       tile_pool_tiles=int(0.75 * N * T))
     x, y, th = cloud(rng, N, 200.0, 200.0, sxy=2.0, sth=0.1, th0=0.6)

@@ -23,7 +23,7 @@ capi.check(capi.load_library().slam_fake_lidar_scan(0, capi.ptr(m01), m01.shape[
 ang = np.arange(B) * (2 * np.pi / B) - np.pi
 scans = [(ang, np.where(hits[k, :, 0] != -1, np.hypot(hits[k, :, 1] - sp[k, 1], hits[k, :, 0] - sp[k, 0]), 500.0)) for k in range(len(poses))]
 CR = int(os.environ.get("SB_ROWS", C))
-variants = [("wave", capi.RAYCAST_FAST_BEAM_LANES, capi.MAPS_DENSE), ("tiled", capi.RAYCAST_FAST, capi.MAPS_TILED)]
+variants = [("wave", capi.RAYCAST_FAST_BEAM_LANES, capi.MAPS_DENSE), ("tiled", capi.RAYCAST_FAST, capi.MAPS_TILED)]  # dense is asked for explicitly: tiles are the default
 if os.environ.get("SB_THREAD", "0") == "1":
     variants.append(("thread", capi.RAYCAST_FAST_PARTICLE_LANES, capi.MAPS_DENSE))
 if os.environ.get("SB_ONLY"):

@@ -17,7 +17,8 @@ while time.time() - t0 < budget:
     T = ((rows + 63) // 64) * ((cols + 63) // 64)
     pool = 0 if rng.random() < 0.5 else int(1.5 * N * T) + 8
     mk = lambda **kw: sa.Filter(N, rows, cols, mode=capi.MODE_SLAM, seed=seed, **kw)
-    fs = {"wave": mk(raycaster=capi.RAYCAST_FAST_BEAM_LANES), "thread": mk(raycaster=capi.RAYCAST_FAST_PARTICLE_LANES),
+    fs = {"wave": mk(raycaster=capi.RAYCAST_FAST_BEAM_LANES, map_storage=capi.MAPS_DENSE),
+          "thread": mk(raycaster=capi.RAYCAST_FAST_PARTICLE_LANES, map_storage=capi.MAPS_DENSE),
           "tiled": mk(map_storage=capi.MAPS_TILED, tile_pool_tiles=pool)}
     x = cols / 2 + rng.choice([1.0, 30.0, 400.0]) * rng.standard_normal(N); y = rows / 2 + rng.choice([1.0, 30.0]) * rng.standard_normal(N)
     th = rng.uniform(-3, 3, N)
