@@ -23,6 +23,12 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// value of `v` in lane `l` for a wave-uniform l: a scalar read instead of an LDS permute
+__device__ __forceinline__ int bcast_i32(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ __forceinline__ double bcast_f64(double v, int l) { return readlane_f64(v, __builtin_amdgcn_readfirstlane(l)); }
+// value of `v` one lane below (lane 0 keeps its own): a DPP wave shift instead of an LDS permute
+__device__ __forceinline__ int lane_below_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+
 // ------------------------------------------------------------------------------------------------
 struct PredictArgs
 {
@@ -484,7 +490,7 @@ __device__ __forceinline__ void wave_pass_prepare(const MAP& map, int rows, int 
     ps->Y = Yb;
     slam_advance(&ps->X, &ps->Y, dx, dy, lane + 1);  // sample k0 + lane + 1, exact
     slam_cell_of(rows, ps->X.v, ps->Y.v, &ps->i, &ps->j);
-    int qi = __shfl_up(ps->i, 1, 64), qj = __shfl_up(ps->j, 1, 64);
+    int qi = lane_below_i32(ps->i), qj = lane_below_i32(ps->j);
     if (lane == 0)
     {
         qi = pi;
@@ -528,13 +534,13 @@ __device__ __forceinline__ void ray_walk_wave(MAP map, int rows, int cols, doubl
         WavePass nxt = cur;
         if (more)
         {
-            Xb.v = __shfl(cur.X.v, 63, 64);
-            Xb.inc = __shfl(cur.X.inc, 63, 64);
-            Xb.rem = __shfl(cur.X.rem, 63, 64);
-            Yb.v = __shfl(cur.Y.v, 63, 64);
-            Yb.inc = __shfl(cur.Y.inc, 63, 64);
-            Yb.rem = __shfl(cur.Y.rem, 63, 64);
-            wave_pass_prepare(map, rows, cols, Xb, Yb, __shfl(cur.i, 63, 64), __shfl(cur.j, 63, 64), dx, dy, k0 + 64,
+            Xb.v = bcast_f64(cur.X.v, 63);
+            Xb.inc = bcast_f64(cur.X.inc, 63);
+            Xb.rem = bcast_i32(cur.X.rem, 63);
+            Yb.v = bcast_f64(cur.Y.v, 63);
+            Yb.inc = bcast_f64(cur.Y.inc, 63);
+            Yb.rem = bcast_i32(cur.Y.rem, 63);
+            wave_pass_prepare(map, rows, cols, Xb, Yb, bcast_i32(cur.i, 63), bcast_i32(cur.j, 63), dx, dy, k0 + 64,
                               max_iter, lane, &nxt);
         }
         const int i = cur.i, j = cur.j, last_exist = cur.last_exist;
@@ -559,9 +565,9 @@ __device__ __forceinline__ void ray_walk_wave(MAP map, int rows, int cols, doubl
         if (lim > last_exist) lim = last_exist;
         if (!found && f_hit <= lim)
         {
-            out->hx = __shfl(cur.X.v, f_hit, 64);
-            out->hy = __shfl(cur.Y.v, f_hit, 64);
-            out->hcell = __shfl(i, f_hit, 64) * cols + __shfl(j, f_hit, 64);
+            out->hx = bcast_f64(cur.X.v, f_hit);
+            out->hy = bcast_f64(cur.Y.v, f_hit);
+            out->hcell = bcast_i32(i, f_hit) * cols + bcast_i32(j, f_hit);
             found = true;
         }
         const bool proc = isnew && lane <= lim;
@@ -631,10 +637,10 @@ __global__ void __launch_bounds__(256) k_weights_S_wave(WeightArgs a, TileArgs t
         {
             WaveRay wr;
             if (TILED)
-                ray_walk_wave(tmap, a.rows, a.cols, sx, sy, __shfl(mydx, q, 64), __shfl(mydy, q, 64), __shfl(myz2, q, 64),
+                ray_walk_wave(tmap, a.rows, a.cols, sx, sy, bcast_f64(mydx, q), bcast_f64(mydy, q), bcast_f64(myz2, q),
                               a.zmax2, luts, luts + 256, a.max_iter, lane, &wr);
             else
-                ray_walk_wave(dmap, a.rows, a.cols, sx, sy, __shfl(mydx, q, 64), __shfl(mydy, q, 64), __shfl(myz2, q, 64),
+                ray_walk_wave(dmap, a.rows, a.cols, sx, sy, bcast_f64(mydx, q), bcast_f64(mydy, q), bcast_f64(myz2, q),
                               a.zmax2, luts, luts + 256, a.max_iter, lane, &wr);
             if (lane == q)
             {
