@@ -70,5 +70,11 @@ int main(int argc, char** argv)
     const slam::Pose avg = slam::average_pose(ps);
     std::printf("MAP %d %d %016llx\nAVG %.17g %.17g %.17g\nREAL %.17g %.17g %.17g\n", best.rows, best.cols, sum, avg.x, avg.y, avg.theta,
                 real_position.x, real_position.y, real_position.theta);
+    // the other free functions of slam/motion.h and slam/util.h (deterministic with zero alphas / fixed arguments)
+    const slam::Pose v = slam::sample_motion_model_velocity({2.0, 0.5}, {10.0, 20.0, 0.3}, 0.25);
+    const double tri = slam::sample_triangular_distribution(1.5);
+    std::printf("VEL %.17g %.17g %.17g\nPDF %.17g %.17g %.17g\nTRI %d\n", v.x, v.y, v.theta, slam::pdf_normal_distribution(2.0, 0.7),
+                slam::pdf_normal_distribution_clamp(2.0, 9.0), slam::pdf_triangular_distribution(1.5, 0.5),
+                (std::fabs(tri) <= 1.5 * (std::sqrt(6.0) / 2 + 1)) ? 1 : 0);
     return 0;
 }

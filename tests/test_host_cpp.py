@@ -66,3 +66,10 @@ def test_cpp_shim_matches_python_path(tmp_path, storage):
         hh = (hh * 1099511628211 + v) & 0xFFFFFFFFFFFFFFFF
     assert int(mh, 16) == hh
     f.close()
+    # free functions of the shim against the oracle's restatements
+    vel = [float(t) for t in next(ln for ln in out if ln.startswith("VEL")).split()[1:]]
+    ex = orc.predict_velocity([10.0], [20.0], [0.3], [2.0, 0.5], 0.25, [0.0] * 6, [0.0, 0.0, 0.0])
+    assert vel == [ex[0][0], ex[1][0], ex[2][0]]
+    pdf = [float(t) for t in next(ln for ln in out if ln.startswith("PDF")).split()[1:]]
+    assert abs(pdf[0] - 0.18762017345846896) < 1e-15 and pdf[1] == 0.0 and pdf[2] == orc.pdf_triangular(1.5, [0.5])[0]
+    assert next(ln for ln in out if ln.startswith("TRI")).split()[1] == "1"
