@@ -42,7 +42,7 @@ def reference_run(n_total, steps):
     return {"x": x, "y": y, "th": th, "w": w, "idx": idx}
 
 
-@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("world", [1, 2, 4])
 def test_sharded_filter_gloo_matches_unsharded(tmp_path, world):
     n_total, steps = 500, 3   # 250 per rank: not a multiple of the 64-chunks of the blocked running sum
     got = run_world(tmp_path, world, n_total, steps)
@@ -70,7 +70,7 @@ def reference_run_slam(n_total, steps):
     return {"x": x, "y": y, "th": th, "w": w, "idx": idx, "maps": maps}
 
 
-@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("world", [1, 2, 4])
 def test_sharded_slam_mode_gloo_matches_unsharded(tmp_path, world):
     """SLAM mode: the canvases of the selected particles cross ranks (all-to-all) and every rank ends
     up with exactly the canvases the unsharded filter holds in those slots."""
