@@ -1050,6 +1050,73 @@ __global__ void __launch_bounds__(256) k_untile(const uint8_t* pool, const int32
     out[k] = pool[(size_t)id * TILE_BYTES + (size_t)tile_cell(i, j)];
 }
 
+// Sharded exchange of tiled canvases travels as dense canvases (slam_amd/dist.py): export of the
+// requested particles, grid (cells / 256, count) ...
+__global__ void __launch_bounds__(256) k_untile_many(const uint8_t* pool, const int32_t* tab, int T, int tcols, int rows, int cols,
+                                                     const int32_t* local_idx, size_t stride, uint8_t* out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (int64_t)rows * cols) return;
+    const int32_t* tab_p = tab + (size_t)local_idx[blockIdx.y] * T;
+    const int i = (int)(k / cols), j = (int)(k - (int64_t)i * cols);
+    const int id = tab_p[(i >> TILE_SHIFT) * tcols + (j >> TILE_SHIFT)] & ~TILE_OWN;
+    out[stride * blockIdx.y + k] = pool[(size_t)id * TILE_BYTES + (size_t)tile_cell(i, j)];
+}
+
+// ... and import of slot p's canvas = dense canvas pos[p] of the received pool, grid (tiles, slots): a tile
+// that is blank (all 128) maps to tile 0, any other becomes a fresh tile (ownership is settled by
+// the census that follows).
+__global__ void __launch_bounds__(256) k_tile_import_many(const uint8_t* dense_pool, const int32_t* pos, size_t stride, int rows,
+                                                          int cols, int32_t* tab, int T, int tcols, uint8_t* pool,
+                                                          const int32_t* freelist, int* ctrl)
+{
+    __shared__ int nid_s, any_s;
+    const int t = blockIdx.x;
+    const size_t p = blockIdx.y;
+    const uint8_t* dense = dense_pool + stride * (size_t)pos[p];
+    const int ti = t / tcols, tj = t - ti * tcols;
+    if (threadIdx.x == 0) any_s = 0;
+    __syncthreads();
+    uint8_t mine[TILE_BYTES / 256];
+    bool nonblank = false;
+#pragma unroll
+    for (int u = 0; u < TILE_BYTES / 256; ++u)
+    {
+        const int q = threadIdx.x + u * 256;
+        const int i = (ti << TILE_SHIFT) + (q >> TILE_SHIFT), j = (tj << TILE_SHIFT) + (q & TILE_MASK);
+        mine[u] = (i < rows && j < cols) ? dense[(size_t)i * cols + j] : (uint8_t)128;
+        nonblank |= mine[u] != 128;
+    }
+    if (nonblank) any_s = 1;
+    __syncthreads();
+    if (!any_s)
+    {
+        if (threadIdx.x == 0) tab[p * T + t] = 0;
+        return;
+    }
+    if (threadIdx.x == 0)
+    {
+        const int pos_f = atomicAdd(&ctrl[0], 1);
+        nid_s = pos_f < ctrl[1] ? freelist[pos_f] : -1;
+        if (nid_s < 0) ctrl[2] = 1;
+    }
+    __syncthreads();
+    const int nid = nid_s;
+    if (nid < 0)
+    {
+        if (threadIdx.x == 0) tab[p * T + t] = 0;
+        return;
+    }
+    uint8_t* to = pool + (size_t)nid * TILE_BYTES;
+#pragma unroll
+    for (int u = 0; u < TILE_BYTES / 256; ++u)
+    {
+        const int q = threadIdx.x + u * 256;
+        to[tile_cell(q >> TILE_SHIFT, q & TILE_MASK)] = mine[u];
+    }
+    if (threadIdx.x == 0) tab[p * T + t] = nid;
+}
+
 // one block per tile of ONE particle: a fresh owned tile filled from the dense canvas (128 beyond its edges)
 __global__ void __launch_bounds__(256) k_tile_import(const uint8_t* dense, int rows, int cols, int32_t* tab_p, int tcols,
                                                      uint8_t* pool, const int32_t* freelist, int* ctrl)

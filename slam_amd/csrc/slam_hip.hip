@@ -535,8 +535,6 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
         return fail(SLAM_ERR_STATE, "resample: shards * n_particles != global_n (sharded handles must use slam_mcl_shard_resample)");
     if (n_shards > 1 && (h->prm.sort != SLAM_SORT_NONE || h->prm.prefix_order != SLAM_PREFIX_BLOCKED))
         return fail(SLAM_ERR_STATE, "sharded resampling needs SLAM_SORT_NONE and SLAM_PREFIX_BLOCKED");
-    if (h->tiled && (n_shards > 1 || !clone_local))
-        return fail(SLAM_ERR_STATE, "SLAM_MAPS_TILED handles do not shard yet");
     if (n_shards > 1 && h->prm.mode == SLAM_MODE_SLAM && clone_local)
         return fail(SLAM_ERR_STATE, "SLAM-mode shards: use slam_mcl_shard_select + slam_mcl_shard_clone_maps");
     slamk::StateView view;
@@ -756,8 +754,8 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
         h->tile_T = ((h->rows + 63) / 64) * h->tile_tc;
         const int64_t dflt = (3 * n * h->tile_T + 1) / 2 + 1;
         h->tile_cap = h->prm.tile_pool_tiles > 0 ? h->prm.tile_pool_tiles + 1 : dflt;  // + the blank tile 0
-        if (h->tile_cap >= (int64_t)slamk::TILE_OWN || n * h->tile_T >= 2147483647LL || n != h->n_glob)
-            rc = fail(SLAM_ERR_ARG, "tiled canvases: pool or tables too large, or a shard (not supported yet)");
+        if (h->tile_cap >= (int64_t)slamk::TILE_OWN || n * h->tile_T >= 2147483647LL)
+            rc = fail(SLAM_ERR_ARG, "tiled canvases: pool or tables too large");
         TRY(dev_alloc(&h->tile_pool, (size_t)h->tile_cap * slamk::TILE_BYTES));
         TRY(dev_alloc(&h->tile_tab, (size_t)n * h->tile_T));
         TRY(dev_alloc(&h->tile_tab2, (size_t)n * h->tile_T));
@@ -1059,10 +1057,24 @@ SLAM_API int slam_mcl_pack_maps(slam_mcl* h, const int32_t* local_idx_dev, int64
 {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (h->prm.mode != SLAM_MODE_SLAM || h->tiled) return fail(SLAM_ERR_STATE, "pack_maps: SLAM mode with dense canvases only");
-    if (count < 0 || count > 2147483647LL || (count > 0 && (!local_idx_dev || !out_dev)))
+    if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "pack_maps: SLAM mode only");
+    if (count < 0 || count > 65535LL * 32768 || (count > 0 && (!local_idx_dev || !out_dev)))
         return fail(SLAM_ERR_ARG, "pack_maps: bad count or null pointer");
-    if (count > 0)
+    if (count > 0 && h->tiled)
+    {
+        // tiled canvases travel as dense ones (row-major, map_stride bytes apart)
+        slam_mcl::Span span(h, G_CLONE);
+        const int64_t cells = (int64_t)h->rows * h->cols;
+        for (int64_t c0 = 0; c0 < count; c0 += 65535)
+        {
+            const int64_t cn = std::min<int64_t>(65535, count - c0);
+            hipLaunchKernelGGL(slamk::k_untile_many, dim3((unsigned)cdiv(cells, 256), (unsigned)cn), dim3(256), 0, h->stream,
+                               h->tile_pool, h->tile_tab, h->tile_T, h->tile_tc, h->rows, h->cols, local_idx_dev + c0,
+                               h->map_stride, out_dev + h->map_stride * (size_t)c0);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    else if (count > 0)
     {
         slam_mcl::Span span(h, G_CLONE);
         launch_clone(h, h->maps, out_dev, local_idx_dev, count);
@@ -1078,6 +1090,25 @@ SLAM_API int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, con
     if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "shard_clone_maps: SLAM mode only");
     if (!h->maps_pending) return fail(SLAM_ERR_STATE, "shard_clone_maps: no slam_mcl_shard_select pending");
     if (!pool_dev || !pos_dev) return fail(SLAM_ERR_ARG, "shard_clone_maps: null pointer");
+    if (h->tiled)
+    {
+        // every tile of the old canvases becomes free, then each slot imports its received canvas (blank
+        // tiles map to tile 0); the census then finds all imported tiles exclusively owned
+        slam_mcl::Span span(h, G_CLONE);
+        HIPCHK(hipMemsetAsync(h->tile_tab, 0, sizeof(int32_t) * (size_t)h->n * h->tile_T, h->stream));
+        if ((rc = tile_collect(h, nullptr))) return rc;
+        for (int64_t p0 = 0; p0 < h->n; p0 += 65535)
+        {
+            const int64_t pn = std::min<int64_t>(65535, h->n - p0);
+            hipLaunchKernelGGL(slamk::k_tile_import_many, dim3((unsigned)h->tile_T, (unsigned)pn), dim3(256), 0, h->stream, pool_dev,
+                               pos_dev + p0, h->map_stride, h->rows, h->cols, h->tile_tab + (size_t)p0 * h->tile_T, h->tile_T,
+                               h->tile_tc, h->tile_pool, h->tile_free, h->tile_ctrl);
+        }
+        HIPCHK(hipGetLastError());
+        if ((rc = tile_collect(h, nullptr))) return rc;
+        h->maps_pending = false;
+        return maybe_finish(h);
+    }
     {
         slam_mcl::Span span(h, G_CLONE);
         launch_clone(h, pool_dev, h->maps2, pos_dev, h->n);
@@ -1106,7 +1137,6 @@ SLAM_API int slam_mcl_get_tile_stats(slam_mcl* h, int64_t out[3])
 SLAM_API int slam_mcl_device_maps_get(slam_mcl* h, slam_mcl_device_maps* out)
 {
     if (!h || !out) return fail(SLAM_ERR_ARG, "null");
-    if (h->tiled) return fail(SLAM_ERR_STATE, "device_maps_get: the handle holds tiled canvases");
     out->maps_dev = h->maps;
     out->idx_dev = h->idx;
     out->map_stride = (int64_t)h->map_stride;

@@ -469,9 +469,6 @@ def test_tiled_pool_exhaustion_is_reported(sa):
     with pytest.raises(RuntimeError, match="tile pool exhausted"):
         f.update(ang, dist, 5.0, 500.0, OFFSET)
     f.close()
-    with pytest.raises(RuntimeError):   # shards of tiled canvases are not built yet: refused, not wrong
-        sa.Filter(64, rows, cols, mode=sa.capi.MODE_SLAM, map_storage=sa.capi.MAPS_TILED, sort=sa.capi.SORT_NONE,
-                  global_first=0, global_n=128)
 
 
 @pytest.mark.parametrize("order", ["blocked", "reference"])
@@ -666,8 +663,8 @@ def test_sharded_filter_matches_single_handle(sa, shards):
     assert_bits(sf.b.f.poses()[0], ox[idx], "ShardedFilter world=1")
 
 
-@pytest.mark.parametrize("shards", [2, 4])
-def test_sharded_slam_mode_matches_single_handle(sa, shards):
+@pytest.mark.parametrize("shards,storage", [(2, "dense"), (4, "dense"), (2, "tiled"), (4, "tiled")])
+def test_sharded_slam_mode_matches_single_handle(sa, shards, storage):
     """SLAM-mode shards: select, canvas exchange (emulated here on one device: what the two small
     all-to-alls and the canvas all-to-all of slam_amd.dist deliver), clone.  Poses, weights and every
     canvas equal the single handle's and the oracle's."""
@@ -684,7 +681,8 @@ def test_sharded_slam_mode_matches_single_handle(sa, shards):
     single = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed, sort=sa.capi.SORT_NONE)
     single.set_poses(x, y, th)
     n_loc = N // shards
-    backs = [HipShard(n_loc, rows, cols, r, shards, 0, seed, mode=sa.capi.MODE_SLAM) for r in range(shards)]
+    st = {"dense": sa.capi.MAPS_DENSE, "tiled": sa.capi.MAPS_TILED}[storage]
+    backs = [HipShard(n_loc, rows, cols, r, shards, 0, seed, mode=sa.capi.MODE_SLAM, map_storage=st) for r in range(shards)]
     for r, b in enumerate(backs):
         b.f.set_poses(x[r * n_loc:(r + 1) * n_loc], y[r * n_loc:(r + 1) * n_loc], th[r * n_loc:(r + 1) * n_loc])
     state, maps = (x, y, th), np.full((N, rows, cols), 128, np.uint8)
@@ -722,7 +720,7 @@ def test_sharded_slam_mode_matches_single_handle(sa, shards):
             assert np.array_equal(backs[p // n_loc].f.map_of(p % n_loc), maps[p]), f"shard canvas {p}, step {step}"
     assert len(np.unique(maps.reshape(N, -1), axis=0)) > 1
     # the driver class itself with world = 1 (pack + clone through the same entry points)
-    sf = ShardedFilter(HipShard(N, rows, cols, 0, 1, 0, seed, mode=sa.capi.MODE_SLAM), world=1)
+    sf = ShardedFilter(HipShard(N, rows, cols, 0, 1, 0, seed, mode=sa.capi.MODE_SLAM, map_storage=st), world=1)
     sf.b.f.set_poses(x, y, th)
     m1 = np.full((N, rows, cols), 128, np.uint8)
     sf.predict(odom, ALPHAS)
