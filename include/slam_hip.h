@@ -195,9 +195,31 @@ int slam_mcl_shard_resample(slam_mcl* h, const double* gathered_state_dev, int32
 int slam_mcl_shard_select(slam_mcl* h, const double* gathered_state_dev, int32_t n_shards);
 int slam_mcl_pack_maps(slam_mcl* h, const int32_t* local_idx_dev, int64_t count, uint8_t* out_dev);
 int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, const int32_t* pos_dev);
+/* The same exchange for SLAM_MAPS_TILED handles.  slam_mcl_pack_maps / slam_mcl_shard_clone_maps work
+ * on them as well (canvases then travel dense; blank tiles stay shared on arrival), but a tiled
+ * shard normally holds far more canvases than would fit dense, so steps 2 and 3 have a sparse
+ * form: a requested canvas travels as its table (SLAM_TILES_PER_CANVAS(rows, cols) int32: 0 = blank
+ * tile, k > 0 = the k-th tile of the payload) and every distinct SLAM_TILE_BYTES tile those tables
+ * name travels once, copy-on-write sharing between the requested canvases included.
+ *   2'. slam_mcl_pack_tiles_count (how many tiles the request needs: the caller sizes the buffers),
+ *       then slam_mcl_pack_tiles with the same arguments: tabs_out_dev[c] = table of canvas
+ *       local_idx_dev[c], tiles_out_dev = the n_tiles payload tiles;
+ *   3'. slam_mcl_shard_import_tiles: tabs_dev/tiles_dev = the received tables and tiles of all owners
+ *       (the caller has shifted each owner's table entries by the position of that owner's first tile
+ *       in tiles_dev); canvas of local slot k = table pos_dev[k].  Slots cloned from one source share
+ *       its tiles until they write.  SLAM_ERR_NOMEM if the pool is smaller than n_tiles.
+ * No reference counterpart beyond the resample loop cited above: the reference keeps whole canvases. */
+#define SLAM_TILE_SIDE 64
+#define SLAM_TILE_BYTES 4096
+#define SLAM_TILES_PER_CANVAS(rows, cols) ((((rows) + 63) / 64) * (((cols) + 63) / 64))
+int slam_mcl_pack_tiles_count(slam_mcl* h, const int32_t* local_idx_dev, int64_t count, int64_t* n_tiles_out);
+int slam_mcl_pack_tiles(slam_mcl* h, const int32_t* local_idx_dev, int64_t count, int32_t* tabs_out_dev,
+                        uint8_t* tiles_out_dev, int64_t n_tiles);
+int slam_mcl_shard_import_tiles(slam_mcl* h, const int32_t* tabs_dev, const uint8_t* tiles_dev, int64_t n_tiles,
+                                const int32_t* pos_dev);
 typedef struct slam_mcl_device_maps
 {
-    uint8_t* maps_dev;       /* n_particles canvases, map_stride bytes apart (rows*cols valid bytes each) */
+    uint8_t* maps_dev;       /* n_particles canvases, map_stride bytes apart (rows*cols valid bytes each); NULL if tiled */
     const int32_t* idx_dev;  /* global source index per local slot, from the last select */
     int64_t map_stride;
     int64_t n_particles;

@@ -14,6 +14,7 @@ PREFIX_BLOCKED, PREFIX_REFERENCE = 0, 1
 RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
 SORT_FULL, SORT_NONE = 0, 1
 WEIGHT_LINEAR, WEIGHT_LOG = 0, 1
+TILE_SIDE, TILE_BYTES = 64, 4096  # SLAM_TILE_SIDE, SLAM_TILE_BYTES of include/slam_hip.h
 MAPS_AUTO, MAPS_DENSE, MAPS_TILED = 0, 1, 2
 RAYCAST_FAST, RAYCAST_WALK, RAYCAST_FAST_BEAM_LANES, RAYCAST_FAST_PARTICLE_LANES = 0, 1, 2, 3
 
@@ -90,6 +91,9 @@ SYMBOLS = {
     "slam_mcl_shard_select": (ctypes.c_int, [_P, _P, _I32]),
     "slam_mcl_pack_maps": (ctypes.c_int, [_P, _P, _I64, _P]),
     "slam_mcl_shard_clone_maps": (ctypes.c_int, [_P, _P, _P]),
+    "slam_mcl_pack_tiles_count": (ctypes.c_int, [_P, _P, _I64, _P]),
+    "slam_mcl_pack_tiles": (ctypes.c_int, [_P, _P, _I64, _P, _P, _I64]),
+    "slam_mcl_shard_import_tiles": (ctypes.c_int, [_P, _P, _P, _I64, _P]),
     "slam_mcl_device_maps_get": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_tile_stats": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_poses": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64]),

@@ -1050,6 +1050,72 @@ __global__ void __launch_bounds__(256) k_untile(const uint8_t* pool, const int32
     out[k] = pool[(size_t)id * TILE_BYTES + (size_t)tile_cell(i, j)];
 }
 
+// Sparse form of the sharded canvas exchange (slam_mcl_pack_tiles / slam_mcl_shard_import_tiles): a
+// requested canvas travels as its table, renumbered into the payload, and every distinct tile the
+// requested tables name travels once.
+// k_pack_mark: one thread per (requested canvas, table entry); the first thread to stamp a tile with
+// this pack's number gives it the next payload position (one atomic per wavefront on the counter).
+__global__ void __launch_bounds__(256) k_pack_mark(const int32_t* tab, int T, const int32_t* local_idx, int64_t total, int gen,
+                                                   int* stamp, int32_t* slot, int32_t* list, int* counter)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int id = 0;
+    if (k < total)
+    {
+        const int64_t c = k / T;
+        id = tab[(size_t)local_idx[c] * T + (size_t)(k - c * T)] & ~TILE_OWN;
+    }
+    const bool fresh = id != 0 && atomicExch(&stamp[id], gen) != gen;
+    const uint64_t vote = __ballot(fresh);
+    if (!vote) return;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0));
+    int base = 0;
+    const int leader = __ffsll((long long)vote) - 1;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, __popcll(vote));
+    base = __shfl(base, leader);
+    if (fresh)
+    {
+        slot[id] = base + lane;
+        list[base + lane] = id;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pack_tabs(const int32_t* tab, int T, const int32_t* local_idx, int64_t total,
+                                                   const int32_t* slot, int32_t* out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const int64_t c = k / T;
+    const int id = tab[(size_t)local_idx[c] * T + (size_t)(k - c * T)] & ~TILE_OWN;
+    out[k] = id ? slot[id] + 1 : 0;
+}
+
+// one block per payload tile, 16 bytes per thread; ids == nullptr: tile q itself
+__global__ void __launch_bounds__(256) k_tiles_copy(const uint8_t* from, const int32_t* from_ids, uint8_t* to, const int32_t* to_ids)
+{
+    const size_t q = blockIdx.x;
+    const uint4* f = reinterpret_cast<const uint4*>(from + (from_ids ? (size_t)from_ids[q] : q) * TILE_BYTES);
+    uint4* t = reinterpret_cast<uint4*>(to + (to_ids ? (size_t)to_ids[q] : q) * TILE_BYTES);
+    t[threadIdx.x] = f[threadIdx.x];
+}
+
+// slot p takes row pos[p] of the received tables; entry e > 0 = payload tile e - 1, now pool tile ids[e - 1]
+__global__ void __launch_bounds__(256) k_import_tabs(const int32_t* tabs, const int32_t* pos, int T, int64_t total, int n_tiles,
+                                                     const int32_t* ids, int32_t* tab, int* ctrl)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const int64_t p = k / T;
+    const int e = tabs[(size_t)pos[p] * T + (size_t)(k - p * T)];
+    if (e < 0 || e > n_tiles)
+    {
+        ctrl[2] = 1;  // a table that names a tile outside the payload
+        tab[k] = 0;
+        return;
+    }
+    tab[k] = e ? ids[e - 1] : 0;
+}
+
 // Sharded exchange of tiled canvases travels as dense canvases (slam_amd/dist.py): export of the
 // requested particles, grid (cells / 256, count) ...
 __global__ void __launch_bounds__(256) k_untile_many(const uint8_t* pool, const int32_t* tab, int T, int tcols, int rows, int cols,

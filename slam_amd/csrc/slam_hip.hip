@@ -92,6 +92,11 @@ struct slam_mcl
     uint8_t* tile_dense = nullptr;     // one dense canvas (import / export staging)
     float* tile_sector = nullptr;      // 256 sectors of the scan frame: how far the current scan can write
     int tile_gen = 0;  // number of the last collection: a tile is referenced iff its mark equals it
+    int *pack_stamp = nullptr, *pack_ctr = nullptr;  // sparse canvas exchange: per tile the number of the pack that listed it
+    int32_t* pack_slot = nullptr;                    // ... and its position in that pack's payload
+    int pack_gen = 0;
+    int64_t pack_tiles = -1, pack_count = -1;        // what the last slam_mcl_pack_tiles_count found, for whom
+    const int32_t* pack_idx = nullptr;
     bool maps_pending = false;  // SLAM-mode shard: poses resampled, canvases not yet (shard_select done)
     // scan
     int Bcap = 0;
@@ -622,7 +627,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
                     h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
                     h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->wlin, h->wmax,
                     h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_who, h->tile_shared, h->tile_ctrl, h->tile_dense, h->tile_sector,
-                    h->tile_wl_p, h->tile_wl_t};
+                    h->tile_wl_p, h->tile_wl_t, h->pack_stamp, h->pack_ctr, h->pack_slot};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (size_t l = 0; l < h->lvl_s.size(); ++l)
@@ -1115,6 +1120,93 @@ SLAM_API int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, con
         HIPCHK(hipGetLastError());
     }
     std::swap(h->maps, h->maps2);
+    h->maps_pending = false;
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_pack_tiles_count(slam_mcl* h, const int32_t* local_idx_dev, int64_t count, int64_t* n_tiles_out)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_SLAM || !h->tiled) return fail(SLAM_ERR_STATE, "pack_tiles: SLAM mode with tiled canvases only");
+    if (!n_tiles_out || count < 0 || (count > 0 && !local_idx_dev) || count * h->tile_T >= (int64_t)256 * 2147483647LL)
+        return fail(SLAM_ERR_ARG, "pack_tiles_count: bad count or null pointer");
+    if (!h->pack_stamp)
+    {
+        rc = dev_alloc(&h->pack_stamp, (size_t)h->tile_cap);
+        if (!rc) rc = dev_alloc(&h->pack_slot, (size_t)h->tile_cap);
+        if (!rc) rc = dev_alloc(&h->pack_ctr, 1);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(h->pack_stamp, 0, sizeof(int) * (size_t)h->tile_cap, h->stream));
+    }
+    int found = 0;
+    if (count > 0)
+    {
+        slam_mcl::Span span(h, G_CLONE);
+        const int64_t total = count * h->tile_T;
+        HIPCHK(hipMemsetAsync(h->pack_ctr, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(slamk::k_pack_mark, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, h->tile_T,
+                           local_idx_dev, total, ++h->pack_gen, h->pack_stamp, h->pack_slot, h->tile_wl_t, h->pack_ctr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&found, h->pack_ctr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->pack_tiles = *n_tiles_out = found;
+    h->pack_count = count;
+    h->pack_idx = local_idx_dev;
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_pack_tiles(slam_mcl* h, const int32_t* local_idx_dev, int64_t count, int32_t* tabs_out_dev,
+                                 uint8_t* tiles_out_dev, int64_t n_tiles)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_SLAM || !h->tiled) return fail(SLAM_ERR_STATE, "pack_tiles: SLAM mode with tiled canvases only");
+    if (count != h->pack_count || n_tiles != h->pack_tiles || local_idx_dev != h->pack_idx)
+        return fail(SLAM_ERR_STATE, "pack_tiles: call slam_mcl_pack_tiles_count with the same canvases first");
+    if ((count > 0 && !tabs_out_dev) || (n_tiles > 0 && !tiles_out_dev)) return fail(SLAM_ERR_ARG, "pack_tiles: null pointer");
+    h->pack_count = h->pack_tiles = -1;
+    if (count > 0)
+    {
+        slam_mcl::Span span(h, G_CLONE);
+        const int64_t total = count * h->tile_T;
+        hipLaunchKernelGGL(slamk::k_pack_tabs, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, h->tile_T,
+                           local_idx_dev, total, h->pack_slot, tabs_out_dev);
+        if (n_tiles > 0)
+            hipLaunchKernelGGL(slamk::k_tiles_copy, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, h->tile_pool, h->tile_wl_t,
+                               tiles_out_dev, (const int32_t*)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_shard_import_tiles(slam_mcl* h, const int32_t* tabs_dev, const uint8_t* tiles_dev, int64_t n_tiles,
+                                         const int32_t* pos_dev)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_SLAM || !h->tiled)
+        return fail(SLAM_ERR_STATE, "shard_import_tiles: SLAM mode with tiled canvases only");
+    if (!h->maps_pending) return fail(SLAM_ERR_STATE, "shard_import_tiles: no slam_mcl_shard_select pending");
+    if (!tabs_dev || !pos_dev || n_tiles < 0 || (n_tiles > 0 && !tiles_dev)) return fail(SLAM_ERR_ARG, "shard_import_tiles: null pointer");
+    if (n_tiles > h->tile_cap - 1)
+        return fail(SLAM_ERR_NOMEM, "shard_import_tiles: " + std::to_string(n_tiles) + " tiles arrive, the pool holds " +
+                                        std::to_string(h->tile_cap - 1) + ": recreate the handle with a larger tile_pool_tiles");
+    slam_mcl::Span span(h, G_CLONE);
+    // every tile of the old canvases becomes free; payload tile q lands in the q-th free tile; slot p
+    // takes the table of its source; the census then settles who owns what (clones share)
+    HIPCHK(hipMemsetAsync(h->tile_tab, 0, sizeof(int32_t) * (size_t)h->n * h->tile_T, h->stream));
+    if ((rc = tile_collect(h, nullptr))) return rc;
+    if (n_tiles > 0)
+        hipLaunchKernelGGL(slamk::k_tiles_copy, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, tiles_dev, (const int32_t*)nullptr,
+                           h->tile_pool, h->tile_free);
+    const int64_t total = (int64_t)h->n * h->tile_T;
+    hipLaunchKernelGGL(slamk::k_import_tabs, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, tabs_dev, pos_dev, h->tile_T,
+                       total, (int)n_tiles, h->tile_free, h->tile_tab, h->tile_ctrl);
+    HIPCHK(hipGetLastError());
+    // the free list is rebuilt by the census, which reads the tables just written
+    if ((rc = tile_collect(h, nullptr))) return rc;
     h->maps_pending = false;
     return maybe_finish(h);
 }

@@ -5,7 +5,8 @@ rank then rebuilds the running sum of all weights in the canonical blocked order
 output slots and copies the selected particles out of the gathered buffer.  The result is
 bit-identical for any number of ranks (tests/test_dist_cpu.py, tests/test_gpu_parity.py).
 In SLAM mode (per-particle canvases) the selected canvases are exchanged as well: one all-to-all of
-whole canvases, each distinct (source, destination rank) pair travelling once.
+whole canvases, each distinct (source, destination rank) pair travelling once.  Shards that hold
+copy-on-write tiled canvases exchange tables and distinct tiles instead (`tiled_wire`).
 
 The per-shard compute is behind a small backend interface so that the collective logic can be
 exercised with `gloo` on CPU tensors in the tests; the product backend is HipShard (libslam_hip.so).
@@ -22,7 +23,7 @@ class HipShard:
 
     def __init__(self, n_local, rows, cols, rank, world, device, seed, stream=None, mode=capi.MODE_LOCALIZATION, **kw):
         if mode == capi.MODE_SLAM:
-            kw.setdefault("map_storage", capi.MAPS_DENSE)  # whole canvases travel between ranks (tiles do not yet)
+            kw.setdefault("map_storage", capi.MAPS_DENSE)
         self.f = Filter(n_local, rows, cols, mode=mode, device=device, seed=seed,
                         sort=capi.SORT_NONE, prefix_order=capi.PREFIX_BLOCKED, global_first=rank * n_local,
                         global_n=world * n_local, stream=stream, **kw)
@@ -30,6 +31,9 @@ class HipShard:
         self.device = torch.device(f"cuda:{device}")
         self.slam_mode = mode == capi.MODE_SLAM
         self.map_stride = int(self.f.device_maps().map_stride) if self.slam_mode else 0
+        # tiled canvases travel as tables + distinct tiles (SLAM_MAPS_TILED; include/slam_hip.h steps 2', 3')
+        self.tiled_wire = self.slam_mode and kw.get("map_storage") == capi.MAPS_TILED
+        self.tiles_per_canvas = ((rows + 63) // 64) * ((cols + 63) // 64)
 
     def set_map(self, grid):
         self.f.set_map(grid)
@@ -63,6 +67,19 @@ class HipShard:
     def clone_maps(self, pool, pos):
         pos32 = pos.to(torch.int32).contiguous()
         self.f.shard_clone_maps(pool.data_ptr(), pos32.data_ptr())
+
+    def pack_tiles(self, local_idx):
+        """(tables (count, tiles_per_canvas) int32, tiles (n_tiles, 4096) uint8) of the requested canvases."""
+        idx32 = local_idx.to(torch.int32).contiguous()
+        n_tiles = self.f.pack_tiles_count(idx32.data_ptr(), idx32.numel())
+        tabs = torch.empty((idx32.numel(), self.tiles_per_canvas), dtype=torch.int32, device=self.device)
+        tiles = torch.empty((n_tiles, capi.TILE_BYTES), dtype=torch.uint8, device=self.device)
+        self.f.pack_tiles(idx32.data_ptr(), idx32.numel(), tabs.data_ptr(), tiles.data_ptr(), n_tiles)
+        return tabs, tiles
+
+    def import_tiles(self, tabs, tiles, pos):
+        pos32 = pos.to(torch.int32).contiguous()
+        self.f.shard_import_tiles(tabs.contiguous().data_ptr(), tiles.contiguous().data_ptr(), tiles.shape[0], pos32.data_ptr())
 
 
 class ShardedFilter:
@@ -106,15 +123,36 @@ class ShardedFilter:
         owner = torch.div(want, n_loc, rounding_mode="floor")
         n_want = torch.bincount(owner, minlength=self.world)
         local_ids = want - owner * n_loc
+        tiled = getattr(self.b, "tiled_wire", False)
         if self.world > 1:
             n_req = torch.empty_like(n_want)
             dist.all_to_all_single(n_req, n_want, group=self.group)
             want_split, req_split = n_want.tolist(), n_req.tolist()
             req = torch.empty(sum(req_split), dtype=local_ids.dtype, device=local_ids.device)
             dist.all_to_all_single(req, local_ids, req_split, want_split, group=self.group)
+            if tiled:
+                # per requester: tables of its canvases + every distinct tile they name, once
+                packs = [self.b.pack_tiles(part) for part in req.split(req_split)]
+                n_send = torch.tensor([t.shape[0] for _, t in packs], dtype=n_want.dtype, device=n_want.device)
+                n_recv = torch.empty_like(n_send)
+                dist.all_to_all_single(n_recv, n_send, group=self.group)
+                send_tabs, send_tiles = torch.cat([a for a, _ in packs]), torch.cat([t for _, t in packs])
+                tabs = torch.empty((want.numel(), send_tabs.shape[1]), dtype=send_tabs.dtype, device=send_tabs.device)
+                dist.all_to_all_single(tabs, send_tabs, want_split, req_split, group=self.group)
+                tiles = torch.empty((int(n_recv.sum()), send_tiles.shape[1]), dtype=torch.uint8, device=send_tiles.device)
+                dist.all_to_all_single(tiles, send_tiles, n_recv.tolist(), n_send.tolist(), group=self.group)
+                # table entries count from 1 within their owner's payload: shift by the owner's first tile
+                base = torch.repeat_interleave(torch.cumsum(n_recv, 0) - n_recv, n_want).to(tabs.dtype)
+                tabs = torch.where(tabs > 0, tabs + base[:, None], tabs)
+                self.b.import_tiles(tabs, tiles, torch.searchsorted(want, idx))
+                return
             send = self.b.pack_maps(req)
             pool = torch.empty((want.numel(), send.shape[1]), dtype=torch.uint8, device=send.device)
             dist.all_to_all_single(pool, send, want_split, req_split, group=self.group)
+        elif tiled:
+            tabs, tiles = self.b.pack_tiles(local_ids)
+            self.b.import_tiles(tabs, tiles, torch.searchsorted(want, idx))
+            return
         else:
             pool = self.b.pack_maps(local_ids)
         self.b.clone_maps(pool, torch.searchsorted(want, idx))

@@ -150,6 +150,20 @@ class Filter:
         check(self.lib.slam_mcl_shard_clone_maps(self._h, ctypes.c_void_p(int(pool_ptr)), ctypes.c_void_p(int(pos_ptr))),
               self.lib)
 
+    def pack_tiles_count(self, local_idx_ptr, count):
+        """Tiled canvases, sparse exchange: how many distinct tiles the `count` requested canvases name."""
+        n = ctypes.c_int64(0)
+        check(self.lib.slam_mcl_pack_tiles_count(self._h, ctypes.c_void_p(int(local_idx_ptr)), count, ctypes.byref(n)), self.lib)
+        return n.value
+
+    def pack_tiles(self, local_idx_ptr, count, tabs_ptr, tiles_ptr, n_tiles):
+        check(self.lib.slam_mcl_pack_tiles(self._h, ctypes.c_void_p(int(local_idx_ptr)), count, ctypes.c_void_p(int(tabs_ptr)),
+                                           ctypes.c_void_p(int(tiles_ptr)), n_tiles), self.lib)
+
+    def shard_import_tiles(self, tabs_ptr, tiles_ptr, n_tiles, pos_ptr):
+        check(self.lib.slam_mcl_shard_import_tiles(self._h, ctypes.c_void_p(int(tabs_ptr)), ctypes.c_void_p(int(tiles_ptr)),
+                                                   n_tiles, ctypes.c_void_p(int(pos_ptr))), self.lib)
+
     def device_maps(self):
         dm = capi.DeviceMaps()
         check(self.lib.slam_mcl_device_maps_get(self._h, ctypes.byref(dm)), self.lib)

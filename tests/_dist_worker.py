@@ -66,6 +66,36 @@ class OracleShard:
     def clone_maps(self, pool, pos):
         self.maps = pool.numpy()[pos.numpy()].reshape((self.n,) + self.maps.shape[1:]).copy()
 
+    # the sparse wire form of tiled canvases (slam_amd.dist, `tiled_wire`), emulated on dense canvases:
+    # 64x64 tiles, blank (all 128) = entry 0, equal tiles of one request travel once
+    tiled_wire = False
+
+    def _as_tiles(self, canv):
+        c, rows, cols = canv.shape
+        tr, tc = (rows + 63) // 64, (cols + 63) // 64
+        pad = np.full((c, tr * 64, tc * 64), 128, np.uint8)
+        pad[:, :rows, :cols] = canv
+        return pad.reshape(c, tr, 64, tc, 64).transpose(0, 1, 3, 2, 4).reshape(c, tr * tc, 4096)
+
+    def pack_tiles(self, local_idx):
+        t = self._as_tiles(self.maps[local_idx.numpy()])
+        tabs = np.zeros(t.shape[:2], np.int32)
+        full = ~(t == 128).all(axis=2)
+        if full.any():
+            uniq, inv = np.unique(t[full], axis=0, return_inverse=True)
+            tabs[full] = inv.reshape(-1) + 1
+        else:
+            uniq = np.zeros((0, 4096), np.uint8)
+        return torch.from_numpy(tabs), torch.from_numpy(np.ascontiguousarray(uniq))
+
+    def import_tiles(self, tabs, tiles, pos):
+        rows, cols = self.maps.shape[1:]
+        tr, tc = (rows + 63) // 64, (cols + 63) // 64
+        payload = np.concatenate([np.full((1, 4096), 128, np.uint8), tiles.numpy()])
+        t = payload[tabs.numpy()[pos.numpy()]]                      # (n, T, 4096)
+        canv = t.reshape(self.n, tr, tc, 64, 64).transpose(0, 1, 3, 2, 4).reshape(self.n, tr * 64, tc * 64)
+        self.maps = np.ascontiguousarray(canv[:, :rows, :cols])
+
     def shard_resample(self, gathered, world):
         g = gathered.numpy().reshape(world, 4, self.n)
         allx, ally, allth, allw = (g[:, q, :].reshape(-1) for q in range(4))
@@ -101,6 +131,7 @@ def main_slam(out, n_total, steps):
     sl = slice(rank * n_loc, (rank + 1) * n_loc)
     shard = OracleShard(n_loc, rank, world, 0x51A4, None, x[sl], y[sl], th[sl])
     shard.enable_slam(SLAM_CANVAS, SLAM_CANVAS)
+    shard.tiled_wire = len(sys.argv) > 5 and sys.argv[5] == "tiles"
     sf = ShardedFilter(shard, world=world)
     ang, dscan = orc.make_scan(slam_room(), SLAM_POSE, SLAM_OFFSET, SLAM_BEAMS, max_dist=SLAM_ZMAX)
     for _ in range(steps):

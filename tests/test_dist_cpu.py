@@ -14,13 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ODOM, ALPHAS, OFFSET = [2.5, 0.02, 0.02], [5e-4, 5e-4, 1e-2, 1e-2], [0.0, 30.0, 0.0]
 
 
-def run_world(tmp_path, world, n_total, steps, mode="loc"):
+def run_world(tmp_path, world, n_total, steps, mode="loc", wire="canvases"):
     out = tmp_path / f"w{world}{mode}"
     out.mkdir()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29500 + world + os.getpid() % 200),
-           os.path.join(HERE, "_dist_worker.py"), str(out), str(n_total), str(steps), mode]
+           os.path.join(HERE, "_dist_worker.py"), str(out), str(n_total), str(steps), mode, wire]
     subprocess.run(cmd, check=True, env=env, timeout=600, capture_output=True)
     parts = [np.load(out / f"rank{r}.npz") for r in range(world)]
     keys = ("x", "y", "th", "w", "idx") + (("maps",) if mode == "slam" else ())
@@ -70,12 +70,13 @@ def reference_run_slam(n_total, steps):
     return {"x": x, "y": y, "th": th, "w": w, "idx": idx, "maps": maps}
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
-def test_sharded_slam_mode_gloo_matches_unsharded(tmp_path, world):
+@pytest.mark.parametrize("world,wire", [(1, "canvases"), (2, "canvases"), (4, "canvases"), (1, "tiles"), (2, "tiles"), (4, "tiles")])
+def test_sharded_slam_mode_gloo_matches_unsharded(tmp_path, world, wire):
     """SLAM mode: the canvases of the selected particles cross ranks (all-to-all) and every rank ends
-    up with exactly the canvases the unsharded filter holds in those slots."""
+    up with exactly the canvases the unsharded filter holds in those slots.  "tiles": the sparse wire
+    form of tiled canvases (tables + distinct tiles, four all-to-alls)."""
     n_total, steps = 128, 3
-    got = run_world(tmp_path, world, n_total, steps, mode="slam")
+    got = run_world(tmp_path, world, n_total, steps, mode="slam", wire=wire)
     ref = reference_run_slam(n_total, steps)
     assert np.array_equal(got["idx"], ref["idx"])
     for k in ("x", "y", "th", "w"):

@@ -663,11 +663,12 @@ def test_sharded_filter_matches_single_handle(sa, shards):
     assert_bits(sf.b.f.poses()[0], ox[idx], "ShardedFilter world=1")
 
 
-@pytest.mark.parametrize("shards,storage", [(2, "dense"), (4, "dense"), (2, "tiled"), (4, "tiled")])
+@pytest.mark.parametrize("shards,storage", [(2, "dense"), (4, "dense"), (2, "tiled"), (4, "tiled"), (2, "tiles"), (4, "tiles")])
 def test_sharded_slam_mode_matches_single_handle(sa, shards, storage):
     """SLAM-mode shards: select, canvas exchange (emulated here on one device: what the two small
     all-to-alls and the canvas all-to-all of slam_amd.dist deliver), clone.  Poses, weights and every
-    canvas equal the single handle's and the oracle's."""
+    canvas equal the single handle's and the oracle's.  "tiled": tiled handles, canvases travel dense;
+    "tiles": tiled handles, tables + distinct tiles travel (slam_mcl_pack_tiles / shard_import_tiles)."""
     import torch
 
     from slam_amd.dist import HipShard, ShardedFilter
@@ -681,7 +682,7 @@ def test_sharded_slam_mode_matches_single_handle(sa, shards, storage):
     single = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed, sort=sa.capi.SORT_NONE)
     single.set_poses(x, y, th)
     n_loc = N // shards
-    st = {"dense": sa.capi.MAPS_DENSE, "tiled": sa.capi.MAPS_TILED}[storage]
+    st = {"dense": sa.capi.MAPS_DENSE, "tiled": sa.capi.MAPS_TILED, "tiles": sa.capi.MAPS_TILED}[storage]
     backs = [HipShard(n_loc, rows, cols, r, shards, 0, seed, mode=sa.capi.MODE_SLAM, map_storage=st) for r in range(shards)]
     for r, b in enumerate(backs):
         b.f.set_poses(x[r * n_loc:(r + 1) * n_loc], y[r * n_loc:(r + 1) * n_loc], th[r * n_loc:(r + 1) * n_loc])
@@ -701,11 +702,23 @@ def test_sharded_slam_mode_matches_single_handle(sa, shards, storage):
         for r, b in enumerate(backs):   # requester r
             want = torch.unique(idxs[r])
             owner = torch.div(want, n_loc, rounding_mode="floor")
+            wants.append(want)
+            if storage == "tiles":
+                tabs, tiles, base = [], [], 0
+                for o in range(shards):
+                    t, p = backs[o].pack_tiles(want[owner == o] - o * n_loc)
+                    tabs.append(torch.where(t > 0, t + base, t))
+                    tiles.append(p)
+                    base += p.shape[0]
+                pools.append((torch.cat(tabs), torch.cat(tiles)))
+                continue
             parts = [backs[o].pack_maps((want[owner == o] - o * n_loc)) for o in range(shards)]
             pools.append(torch.cat(parts))
-            wants.append(want)
         for r, b in enumerate(backs):
-            b.clone_maps(pools[r], torch.searchsorted(wants[r], idxs[r]))
+            if storage == "tiles":
+                b.import_tiles(*pools[r], torch.searchsorted(wants[r], idxs[r]))
+            else:
+                b.clone_maps(pools[r], torch.searchsorted(wants[r], idxs[r]))
         ox, oy, oth = orc.predict(*state, odom, ALPHAS, orc.philox_normals(seed, step, 0, N), math=orc.DET)
         ow, _ = orc.update_weights(ox, oy, oth, maps, ang, dist, 5.0, zmax, OFFSET, slam_mode=True, math=orc.DET)
         idx, _, _ = orc.resample(ow, orc.philox_uniforms(seed, step, 0, N), orc.ORDER_BLOCKED)

@@ -28,6 +28,25 @@ if os.environ.get("SB_THREAD", "0") == "1":
     variants.append(("thread", capi.RAYCAST_FAST_PARTICLE_LANES, capi.MAPS_DENSE))
 if os.environ.get("SB_ONLY"):
     variants = [v for v in variants if v[0] == os.environ["SB_ONLY"]]
+if os.environ.get("SB_ONLY") == "shard":
+    # one tiled shard driven through slam_amd.dist (world 1): select, sparse pack (tables + distinct tiles), import
+    import torch
+    from slam_amd.dist import HipShard, ShardedFilter
+    sf = ShardedFilter(HipShard(N, CR, C, 0, 1, 0, 1234, mode=capi.MODE_SLAM, map_storage=capi.MAPS_TILED,
+                                tile_pool_tiles=int(os.environ.get("SB_POOL", 0))), world=1)
+    sf.b.f.profile(True)
+    for k in range(len(scans)):
+        sf.predict(odom, alphas)
+        sf.update(*scans[k], 5.0, 500.0, bench.OFFSET)
+        if k == 3:
+            sf.b.f.kernel_ms()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+    sf.b.f.synchronize(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (len(scans) - 4) * 1e3
+    km = sf.b.f.kernel_ms()
+    print(f"shard   N={N} canvas={CR}x{C}: {dt:8.3f} ms/step wall;", {k: round(v[0] / max(v[1], 1), 3) for k, v in km.items()},
+          sf.b.f.tile_stats(), flush=True)
+    sys.exit(0)
 for name, rc, storage in variants:
     f = sa.Filter(N, CR, C, mode=capi.MODE_SLAM, raycaster=rc, map_storage=storage,
                   tile_pool_tiles=int(os.environ.get("SB_POOL", 0)) if storage == capi.MAPS_TILED else 0)
