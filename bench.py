@@ -160,7 +160,8 @@ def main():
     else:
         shard = HipShard(n_loc, rows, cols, rank, world, local_rank, SEED, stream=stream, async_launch=True)
         shard.set_map(grid)
-        sf = ShardedFilter(shard, world=world, always_collective=force_sharded and dist.is_initialized())
+        sf = ShardedFilter(shard, world=world, always_collective=force_sharded and dist.is_initialized(),
+                           split_exchange=os.environ.get("BENCH_SPLIT_EXCHANGE", "0") == "1")
         f = shard.f
         step_predict = lambda: sf.predict(ODOM, ALPHAS)
         upd = lambda a, d: sf.update(a, d, STDDEV, MAX_DIST, OFFSET)
@@ -199,6 +200,7 @@ def main():
     for _ in range(args.steps):
         step_predict()
         step_update()
+    host_elapsed = time.perf_counter() - t0   # time to ENQUEUE the steps (diagnostic: is the loop host-bound?)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -254,6 +256,7 @@ def main():
                 "kernel_particle_beams_per_s": n_loc * B / (k_avg_ms * 1e-3),
             },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kms.items()},
+            "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(free, ang, dscan, B)

@@ -180,6 +180,13 @@ int slam_mcl_device_state_get(slam_mcl* h, slam_mcl_device_state* out);
  * handle with n_particles = global_n and SLAM_SORT_NONE, for any number of shards.
  * Requires localization mode, SLAM_SORT_NONE, SLAM_PREFIX_BLOCKED. */
 int slam_mcl_shard_resample(slam_mcl* h, const double* gathered_state_dev, int32_t n_shards);
+/* The same with the exchange split in two, so that three quarters of it leave the critical path: the
+ * poses are final after slam_mcl_predict and can be gathered while the weighting pass runs
+ * (gathered_poses_dev = [n_shards][3][n_particles]: the first 3*n doubles of every shard's
+ * state_dev); only the weights (gathered_weights_dev = [n_shards][n_particles]: the last n doubles)
+ * are gathered after slam_mcl_update_weights.  Same result as slam_mcl_shard_resample. */
+int slam_mcl_shard_resample_split(slam_mcl* h, const double* gathered_poses_dev, const double* gathered_weights_dev,
+                                  int32_t n_shards);
 
 /* Sharded resampling in SLAM mode (per-particle canvases, slam/mcl.cpp:147-155,205-227): the
  * selected particles' canvases live on the shard that owns the source, so the step has an exchange

@@ -89,6 +89,7 @@ SYMBOLS = {
     "slam_mcl_resample": (ctypes.c_int, [_P]),
     "slam_mcl_shard_resample": (ctypes.c_int, [_P, _P, _I32]),
     "slam_mcl_shard_select": (ctypes.c_int, [_P, _P, _I32]),
+    "slam_mcl_shard_resample_split": (ctypes.c_int, [_P, _P, _P, _I32]),
     "slam_mcl_pack_maps": (ctypes.c_int, [_P, _P, _I64, _P]),
     "slam_mcl_shard_clone_maps": (ctypes.c_int, [_P, _P, _P]),
     "slam_mcl_pack_tiles_count": (ctypes.c_int, [_P, _P, _I64, _P]),

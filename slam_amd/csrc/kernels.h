@@ -684,17 +684,20 @@ __global__ void __launch_bounds__(256) k_weights_S_wave(WeightArgs a, TileArgs t
 
 // Particle state is stored packed, [x | y | theta | weight], n doubles each.  A "gathered" buffer
 // holds the packed states of all shards back to back ([shard][4][n_loc]), which is exactly what an
-// all-gather of the per-shard buffers produces.
+// all-gather of the per-shard buffers produces.  Split form (wbase != nullptr): the poses and the
+// weights were gathered separately, base = [shard][3][n_loc], wbase = [shard][n_loc].
 struct StateView
 {
     const double* base;
     int64_t n_loc;  // particles per shard
+    const double* wbase;
 };
 __device__ __forceinline__ double sv_get(const StateView& v, int q, int64_t i)
 {
+    if (v.wbase && q == 3) return v.wbase[i];
     const int64_t r = i / v.n_loc;
     const int64_t o = i - r * v.n_loc;
-    return v.base[(r * 4 + q) * v.n_loc + o];
+    return v.base[(r * (v.wbase ? 3 : 4) + q) * v.n_loc + o];
 }
 
 // SLAM_WEIGHT_LOG: maximum of the weight column of all shards (max is exact, so any reduction order
@@ -836,11 +839,11 @@ __global__ void __launch_bounds__(256) k_gather(StateView view, const int32_t* i
     const int32_t s = idx[perm ? perm[p] : p];
     const int64_t r = s / view.n_loc;
     const int64_t o = s - r * view.n_loc;
-    const double* from = view.base + r * 4 * view.n_loc + o;
+    const double* from = view.base + r * (view.wbase ? 3 : 4) * view.n_loc + o;
     dst[p] = from[0];
     dst[n + p] = from[view.n_loc];
     dst[2 * n + p] = from[2 * view.n_loc];
-    dst[3 * n + p] = from[3 * view.n_loc];
+    dst[3 * n + p] = view.wbase ? view.wbase[s] : from[3 * view.n_loc];
     src[p] = s;
 }
 
@@ -931,6 +934,12 @@ __global__ void __launch_bounds__(256) k_tile_free(const int* ref, int live, int
     for (int q = 0; q < 32; ++q)
         if (mask & (1u << q)) freelist[at++] = id0 + q * 256;
 }
+
+struct SectorTable
+{
+    float r[256];
+};
+__global__ void __launch_bounds__(256) k_set_sectors(SectorTable t, float* out) { out[threadIdx.x] = t.r[threadIdx.x]; }
 
 // Before a weighting pass: every tile a particle may write (within `range` cells of its sensor) that
 // it does not own yet is copied to a fresh tile, instead of one at a time inside k_weights_S_wave.

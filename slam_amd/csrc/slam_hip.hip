@@ -102,7 +102,13 @@ struct slam_mcl
     int Bcap = 0;
     double* scan_dev = nullptr;  // [angle | dist^2 | sqrt(dist^2)], Bcap doubles each (packed at B)
     double *angles = nullptr, *z2 = nullptr, *z = nullptr;
-    std::vector<double> scan_cache, scan_prev;
+    std::vector<double> scan_cache;
+    // pinned staging ring of the scan upload: a copy from pageable memory would make the host wait for
+    // the stream to drain on every update; slot k is reused once its own copy has run
+    enum { SCAN_RING = 4 };
+    double* scan_pin[SCAN_RING] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t scan_ev[SCAN_RING] = {nullptr, nullptr, nullptr, nullptr};
+    int scan_slot = 0;
     int last_B = 0;
     // noise
     double *inj_normals = nullptr, *inj_uniforms = nullptr;
@@ -245,6 +251,13 @@ int upload_scan(slam_mcl* h, const double* angles, const double* dists, int B)
         h->Bcap = 0;
         int rc = dev_alloc(&h->scan_dev, 3 * (size_t)B);
         if (rc) return rc;
+        for (int k = 0; k < slam_mcl::SCAN_RING; ++k)
+        {
+            if (h->scan_pin[k]) hipHostFree(h->scan_pin[k]);
+            h->scan_pin[k] = nullptr;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->scan_pin[k]), sizeof(double) * 3 * (size_t)B, hipHostMallocDefault));
+            if (!h->scan_ev[k]) HIPCHK(hipEventCreateWithFlags(&h->scan_ev[k], hipEventDisableTiming));
+        }
         h->Bcap = B;
         h->scan_cache.clear();
     }
@@ -261,11 +274,14 @@ int upload_scan(slam_mcl* h, const double* angles, const double* dists, int B)
     h->z2 = h->scan_dev + B;
     h->z = h->scan_dev + 2 * (size_t)B;
     if (h->last_B == B && h->scan_cache == pack) return SLAM_OK;  // same scan re-applied (benchmark/mcl.cpp:58-64)
-    // stream-ordered copy from pageable memory: the runtime stages the bytes before returning, so
-    // `pack` may go out of scope and kernels already queued on the stream still see the old scan
-    HIPCHK(hipMemcpyAsync(h->scan_dev, pack.data(), sizeof(double) * 3 * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    // stream-ordered copy out of a pinned slot: kernels already queued on the stream still see the
+    // old scan, and the host does not wait for them
+    const int k = h->scan_slot = (h->scan_slot + 1) % slam_mcl::SCAN_RING;
+    HIPCHK(hipEventSynchronize(h->scan_ev[k]));  // the copy that last used this slot (four uploads ago) has run
+    std::memcpy(h->scan_pin[k], pack.data(), sizeof(double) * 3 * (size_t)B);
+    HIPCHK(hipMemcpyAsync(h->scan_dev, h->scan_pin[k], sizeof(double) * 3 * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->scan_ev[k], h->stream));
     h->scan_cache.swap(pack);
-    h->scan_prev.swap(pack);  // keep the previous host copy alive for one more generation
     h->last_B = B;
     return SLAM_OK;
 }
@@ -354,7 +370,8 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             slamk::TilePlan pl = {h->tile_wl_p, h->tile_wl_t};
             {
                 // per sector of the scan frame (sector k covers angles [-pi + k 2pi/256, ...)): the farthest write
-                float sec[256] = {0.0f}, dil[256];
+                float sec[256] = {0.0f};
+                slamk::SectorTable dil;
                 const double* ang = h->scan_cache.data();
                 const double* zz = ang + 2 * (size_t)B;
                 for (int b = 0; b < B; ++b)
@@ -366,8 +383,9 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                     const float r = (float)(std::fmin(zz[b], a.zmax) + 2.0) * 1.0001f;
                     if (r > sec[k]) sec[k] = r;
                 }
-                for (int k = 0; k < 256; ++k) dil[k] = std::max(sec[k], std::max(sec[(k + 1) & 255], sec[(k + 255) & 255]));
-                HIPCHK(hipMemcpyAsync(h->tile_sector, dil, sizeof(dil), hipMemcpyHostToDevice, h->stream));
+                for (int k = 0; k < 256; ++k) dil.r[k] = std::max(sec[k], std::max(sec[(k + 1) & 255], sec[(k + 255) & 255]));
+                // travels as a kernel argument: a copy from pageable memory would make the host wait for the stream
+                hipLaunchKernelGGL(slamk::k_set_sectors, dim3(1), dim3(256), 0, h->stream, dil, h->tile_sector);
             }
             hipLaunchKernelGGL(slamk::k_tile_mark, dim3(1), dim3(1), 0, h->stream, h->tile_ctrl);
             hipLaunchKernelGGL(slamk::k_tile_plan, dim3((unsigned)h->n), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th, a.sd,
@@ -521,7 +539,6 @@ int do_prefix(slam_mcl* h, const slamk::StateView& view)
     return SLAM_OK;
 }
 
-// `gathered`: packed states of all shards ([n_shards][4][n]); nullptr = this handle alone.
 void launch_clone(slam_mcl* h, const uint8_t* from, uint8_t* to, const int32_t* src, int64_t count)
 {
     const unsigned chunks = (unsigned)std::min<size_t>(cdiv((int64_t)(h->map_stride / 16), 256), 64);
@@ -529,9 +546,11 @@ void launch_clone(slam_mcl* h, const uint8_t* from, uint8_t* to, const int32_t* 
                        h->map_stride);
 }
 
+// `gathered`: packed states of all shards ([n_shards][4][n]); nullptr = this handle alone.
+// `gathered_w` != nullptr: split form, gathered = [n_shards][3][n] poses, gathered_w = [n_shards][n] weights.
 // clone_local = false: SLAM-mode shards; the caller exchanges the canvases and finishes with
 // slam_mcl_shard_clone_maps.
-int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_local = true)
+int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_local = true, const double* gathered_w = nullptr)
 {
     const bool injected = h->prm.noise == SLAM_NOISE_INJECTED;
     if (injected && !h->have_uniforms) return fail(SLAM_ERR_STATE, "injected noise: no uniforms set for this update");
@@ -545,6 +564,7 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
     slamk::StateView view;
     view.base = gathered ? gathered : h->state;
     view.n_loc = n;
+    view.wbase = gathered ? gathered_w : nullptr;
     {
         slam_mcl::Span span(h, G_RESAMPLE);
         int rc = do_prefix(h, view);
@@ -630,6 +650,11 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
                     h->tile_wl_p, h->tile_wl_t, h->pack_stamp, h->pack_ctr, h->pack_slot};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    for (int k = 0; k < slam_mcl::SCAN_RING; ++k)
+    {
+        if (h->scan_pin[k]) hipHostFree(h->scan_pin[k]);
+        if (h->scan_ev[k]) hipEventDestroy(h->scan_ev[k]);
+    }
     for (size_t l = 0; l < h->lvl_s.size(); ++l)
     {
         if (h->lvl_s[l]) hipFree(h->lvl_s[l]);
@@ -1042,6 +1067,17 @@ SLAM_API int slam_mcl_shard_resample(slam_mcl* h, const double* gathered_state_d
     if (rc) return rc;
     if (!gathered_state_dev || n_shards < 1) return fail(SLAM_ERR_ARG, "shard_resample: null buffer or n_shards < 1");
     if ((rc = do_resample(h, gathered_state_dev, n_shards))) return rc;
+    return maybe_finish(h);
+}
+
+SLAM_API int slam_mcl_shard_resample_split(slam_mcl* h, const double* gathered_poses_dev, const double* gathered_weights_dev,
+                                           int32_t n_shards)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!gathered_poses_dev || !gathered_weights_dev || n_shards < 1)
+        return fail(SLAM_ERR_ARG, "shard_resample_split: null buffer or n_shards < 1");
+    if ((rc = do_resample(h, gathered_poses_dev, n_shards, true, gathered_weights_dev))) return rc;
     return maybe_finish(h);
 }
 

@@ -1,6 +1,10 @@
 """One-process-per-GPU sharded filter: particles are split into contiguous shards,
 one per rank; predict and weighting are local; resampling is global and needs ONE exchange step, an
-all-gather of the packed per-shard state (32 B per particle) over RCCL/xGMI (`nccl` backend).  Every
+all-gather of the packed per-shard state (32 B per particle) over RCCL/xGMI (`nccl` backend).
+`split_exchange=True` splits it: the poses (24 B) are final after predict, so their all-gather is
+issued on a side stream and can run under the weighting pass, and only the weights (8 B) are
+gathered on the critical path (off by default: whether the side stream really overlaps depends on
+how the runtime maps streams to hardware queues).  Every
 rank then rebuilds the running sum of all weights in the canonical blocked order, draws its own
 output slots and copies the selected particles out of the gathered buffer.  The result is
 bit-identical for any number of ranks (tests/test_dist_cpu.py, tests/test_gpu_parity.py).
@@ -53,6 +57,9 @@ class HipShard:
     def shard_resample(self, gathered, world):
         self.f.shard_resample(gathered.data_ptr(), world)
 
+    def shard_resample_split(self, gathered_poses, gathered_weights, world):
+        self.f.shard_resample_split(gathered_poses.data_ptr(), gathered_weights.data_ptr(), world)
+
     # SLAM mode: the three local pieces around the canvas exchange
     def shard_select(self, gathered, world):
         self.f.shard_select(gathered.data_ptr(), world)
@@ -85,20 +92,55 @@ class HipShard:
 class ShardedFilter:
     """The filter step over `world` ranks.  `backend` is the local shard (HipShard in production)."""
 
-    def __init__(self, backend, world=None, group=None, always_collective=False):
+    def __init__(self, backend, world=None, group=None, always_collective=False, split_exchange=False):
         self.b = backend
         self.group = group
         self.always_collective = always_collective  # issue the all-gather even for one rank (rehearsal)
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self._gathered = backend.new_gather_buffer(self.world)
         self._stage = None
+        # split exchange (localization mode): poses gathered early on a side stream, weights late
+        self._split = split_exchange and (self.world > 1 or always_collective) and not getattr(backend, "slam_mode", False) \
+            and hasattr(backend, "shard_resample_split")
+        self._gp = self._gw = self._stage_p = self._stage_w = self._comm = self._poses_done = None
 
     def predict(self, odom, alphas):
         self.b.predict(odom, alphas)
+        if self._split:
+            self._gather_poses()
+
+    def _gather_poses(self):
+        """All-gather of [x | y | theta] (final once predict has run), off the critical path."""
+        local = self.b.packed_state()
+        n3 = 3 * (local.numel() // 4)
+        if self._gp is None:
+            self._stage_p, self._stage_w = torch.empty_like(local[:n3]), torch.empty_like(local[n3:])
+            self._gp = torch.empty(self.world * n3, dtype=local.dtype, device=local.device)
+            self._gw = torch.empty(self.world * (local.numel() - n3), dtype=local.dtype, device=local.device)
+            if local.is_cuda:
+                self._comm = torch.cuda.Stream(device=local.device)
+        if self._comm is None:
+            self._stage_p.copy_(local[:n3])
+            dist.all_gather_into_tensor(self._gp, self._stage_p, group=self.group)
+            return
+        # the side stream waits for predict (and, through it, for the previous resample, the last
+        # reader of _gp); the resample of this step waits for _poses_done
+        self._comm.wait_event(torch.cuda.current_stream(local.device).record_event())
+        with torch.cuda.stream(self._comm):
+            self._stage_p.copy_(local[:n3])
+            dist.all_gather_into_tensor(self._gp, self._stage_p, group=self.group)
+            self._poses_done = self._comm.record_event()
 
     def update(self, angles, dists, stddev, max_dist, offset=(0.0, 0.0, 0.0)):
         self.b.update_weights(angles, dists, stddev, max_dist, offset)
         local = self.b.packed_state()
+        if self._split:
+            self._stage_w.copy_(local[self._stage_p.numel():])
+            dist.all_gather_into_tensor(self._gw, self._stage_w, group=self.group)
+            if self._poses_done is not None:
+                torch.cuda.current_stream(local.device).wait_event(self._poses_done)
+            self.b.shard_resample_split(self._gp, self._gw, self.world)
+            return
         if self.world > 1 or self.always_collective:
             # the one exchange step of the path: all-gather of [x | y | theta | w] of every shard.
             # The library's buffer is viewed zero-copy; it is staged through a torch-allocated

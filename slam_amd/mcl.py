@@ -138,6 +138,11 @@ class Filter:
         """gathered_state_ptr: device address of the all-gathered packed states ([n_shards][4][n])."""
         check(self.lib.slam_mcl_shard_resample(self._h, ctypes.c_void_p(int(gathered_state_ptr)), n_shards), self.lib)
 
+    def shard_resample_split(self, gathered_poses_ptr, gathered_weights_ptr, n_shards):
+        """As shard_resample with poses ([n_shards][3][n]) and weights ([n_shards][n]) gathered separately."""
+        check(self.lib.slam_mcl_shard_resample_split(self._h, ctypes.c_void_p(int(gathered_poses_ptr)),
+                                                     ctypes.c_void_p(int(gathered_weights_ptr)), n_shards), self.lib)
+
     def shard_select(self, gathered_state_ptr, n_shards):
         """SLAM-mode shards, step 1: poses and weights resampled, canvases pending (see include/slam_hip.h)."""
         check(self.lib.slam_mcl_shard_select(self._h, ctypes.c_void_p(int(gathered_state_ptr)), n_shards), self.lib)

@@ -96,6 +96,10 @@ class OracleShard:
         canv = t.reshape(self.n, tr, tc, 64, 64).transpose(0, 1, 3, 2, 4).reshape(self.n, tr * 64, tc * 64)
         self.maps = np.ascontiguousarray(canv[:, :rows, :cols])
 
+    def shard_resample_split(self, gathered_poses, gathered_weights, world):
+        g = torch.cat([gathered_poses.reshape(world, 3, self.n), gathered_weights.reshape(world, 1, self.n)], dim=1)
+        self.shard_resample(g.reshape(-1), world)
+
     def shard_resample(self, gathered, world):
         g = gathered.numpy().reshape(world, 4, self.n)
         allx, ally, allth, allw = (g[:, q, :].reshape(-1) for q in range(4))
@@ -156,7 +160,7 @@ def main():
     x, y, th = 520 + 20 * rng.standard_normal(n_total), 280 + 20 * rng.standard_normal(n_total), 0.4 + 0.2 * rng.standard_normal(n_total)
     sl = slice(rank * n_loc, (rank + 1) * n_loc)
     shard = OracleShard(n_loc, rank, world, 0xD157, grid, x[sl], y[sl], th[sl])
-    sf = ShardedFilter(shard, world=world)
+    sf = ShardedFilter(shard, world=world, split_exchange=len(sys.argv) > 5 and sys.argv[5] == "split")
     ang, dscan = orc.make_scan(free, [520.0, 280.0, 0.4], OFFSET, 45)
     for _ in range(steps):
         sf.predict(ODOM, ALPHAS)

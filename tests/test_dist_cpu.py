@@ -42,10 +42,11 @@ def reference_run(n_total, steps):
     return {"x": x, "y": y, "th": th, "w": w, "idx": idx}
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
-def test_sharded_filter_gloo_matches_unsharded(tmp_path, world):
+@pytest.mark.parametrize("world,wire", [(1, "whole"), (2, "whole"), (4, "whole"), (2, "split")])
+def test_sharded_filter_gloo_matches_unsharded(tmp_path, world, wire):
+    """wire = "split": poses gathered after predict, weights after the weighting pass (two all-gathers)."""
     n_total, steps = 500, 3   # 250 per rank: not a multiple of the 64-chunks of the blocked running sum
-    got = run_world(tmp_path, world, n_total, steps)
+    got = run_world(tmp_path, world, n_total, steps, wire=wire)
     ref = reference_run(n_total, steps)
     assert np.array_equal(got["idx"], ref["idx"])
     for k in ("x", "y", "th", "w"):

@@ -607,8 +607,9 @@ def test_full_size_config2_properties(sa):
 
 
 # ---- sharded resampling: any number of shards gives the single-handle result ------------------------
-@pytest.mark.parametrize("shards", [2, 4])
-def test_sharded_filter_matches_single_handle(sa, shards):
+@pytest.mark.parametrize("shards,split", [(2, False), (4, False), (2, True), (4, True)])
+def test_sharded_filter_matches_single_handle(sa, shards, split):
+    """split: poses and weights gathered separately (slam_mcl_shard_resample_split)."""
     import torch
 
     from slam_amd.dist import HipShard, ShardedFilter
@@ -637,9 +638,14 @@ def test_sharded_filter_matches_single_handle(sa, shards):
             b.predict(ODOM, ALPHAS)
             b.update_weights(ang, dist, 5.0, 500.0, OFFSET)
         gathered = torch.cat([b.packed_state() for b in backs])      # what all_gather_into_tensor produces
+        gp = torch.cat([b.packed_state()[:3 * n_loc] for b in backs])
+        gw = torch.cat([b.packed_state()[3 * n_loc:] for b in backs])
         torch.cuda.synchronize()
         for b in backs:
-            b.shard_resample(gathered, shards)
+            if split:
+                b.shard_resample_split(gp, gw, shards)
+            else:
+                b.shard_resample(gathered, shards)
         # oracle, unsorted order
         ox, oy, oth = orc.predict(*state, ODOM, ALPHAS, orc.philox_normals(seed, step, 0, N), math=orc.DET)
         ow, _ = orc.update_weights(ox, oy, oth, g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET)
