@@ -247,10 +247,12 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
 // 1/1024 turn, take nearly the same number of lookups and touch the same cache lines.  Keys wrap
 // (11 bits per axis): far-apart particles that alias only cost coherence, never correctness.
 __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, const double* y, const double* th,
-                                                    int mode, int key_bits, uint32_t* keys, int32_t* ident)
+                                                    int mode, int key_bits, uint32_t* keys, int32_t* ident,
+                                                    unsigned long long* stats)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    if (p < 3) stats[p] = 0;  // the pass's counters start at zero (saves a memset launch)
     // mode = kind | (tile_shift + 1) << 4 | heading_bits << 8 (0 fields: 4-cell tiles, 10 heading bits:
     // best for a converged cloud, 4 % over 2-cell tiles / 8 bits; a wide cloud prefers coarser headings)
     const int kind = mode & 15;
@@ -760,6 +762,49 @@ __global__ void __launch_bounds__(256) k_downsweep(const double* s, const double
     P[j] = c ? Pnext[c - 1] + s[j] : s[j];
 }
 
+// Levels 1 .. L-1 of the hierarchy (everything above the 64-chunks of the weights themselves) are small:
+// one workgroup runs their scans and downsweeps back to back instead of one launch each.  Same
+// operations in the same order as k_scan_chunks / k_downsweep.
+struct UpperLevels
+{
+    int L;  // levels in total (<= 8); level 0 is handled by the caller
+    int64_t n[8];
+    double *s[8], *tot[8], *P[8];
+};
+__global__ void __launch_bounds__(1024) k_scan_upper(UpperLevels u)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int l = 1; l < u.L; ++l)
+    {
+        const double* a = u.tot[l - 1];
+        const int64_t n = u.n[l];
+        for (int64_t c = wave; c * 64 < n; c += 16)
+        {
+            const int64_t i = c * 64 + lane;
+            double v = i < n ? a[i] : 0.0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1)
+            {
+                const double t = __shfl_up(v, d, 64);
+                if (lane >= d) v = t + v;
+            }
+            if (i < n) u.s[l][i] = v;
+            const int64_t last = (c * 64 + 63 < n - 1) ? c * 64 + 63 : n - 1;
+            if (i == last) u.tot[l][c] = v;
+        }
+        __syncthreads();
+    }
+    for (int l = u.L - 2; l >= 1; --l)
+    {
+        for (int64_t j = threadIdx.x; j < u.n[l]; j += 1024)
+        {
+            const int64_t c = j >> 6;
+            u.P[l][j] = c ? u.P[l + 1][c - 1] + u.s[l][j] : u.s[l][j];
+        }
+        __syncthreads();
+    }
+}
+
 // The reference's order (slam/mcl.cpp:170-176): strictly sequential, one thread.
 __global__ void k_prefix_seq(const double* w, int64_t n, double* P)
 {
@@ -783,6 +828,9 @@ struct SelectArgs
     uint64_t seed, step;
     int resampler;
     int32_t* idx;           // n_slots selected global indices
+    StateView view;         // sort keys wanted (keys != nullptr): weight of the particle selected for slot k,
+    double* keys;           // payload k
+    int32_t* slots;
 };
 
 // slam/mcl.cpp:179-203: cutoff = canonical * sum; bisection in which equality returns mid.
@@ -819,15 +867,11 @@ __global__ void __launch_bounds__(256) k_select(SelectArgs a)
             j = mid;
     }
     a.idx[k] = i;
-}
-
-// sort keys: weight of the particle selected for slot k; payload: k
-__global__ void __launch_bounds__(256) k_sort_keys(StateView view, const int32_t* idx, int64_t n, double* keys, int32_t* slots)
-{
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    keys[k] = sv_get(view, 3, idx[k]);
-    slots[k] = (int32_t)k;
+    if (a.keys)
+    {
+        a.keys[k] = sv_get(a.view, 3, i);
+        a.slots[k] = (int32_t)k;
+    }
 }
 
 // src[p] = idx[perm[p]] (perm == nullptr: identity); new state p = old state src[p]

@@ -348,7 +348,11 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.hit_cell = h->record_hits ? h->hit_cell : nullptr;
     a.stats = h->stats;
     a.luts = h->luts;
-    HIPCHK(hipMemsetAsync(h->stats, 0, 3 * sizeof(unsigned long long), h->stream));
+    static const int order_mode = getenv("SLAM_PL_ORDER") ? atoi(getenv("SLAM_PL_ORDER")) : 3;
+    const bool particle_lanes = !slam_mode && (h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES ||
+                                               (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096));
+    if (!(particle_lanes && order_mode > 0 && h->n >= 3))  // k_order_keys zeroes the counters itself
+        HIPCHK(hipMemsetAsync(h->stats, 0, 3 * sizeof(unsigned long long), h->stream));
     slam_mcl::Span span(h, G_WEIGHTS);
     if (slam_mode)
     {
@@ -404,8 +408,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         else
             hipLaunchKernelGGL(slamk::k_weights_S, dim3((unsigned)cdiv(h->n, 64)), dim3(64), 0, h->stream, a);
     }
-    else if (h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES ||
-             (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096))
+    else if (particle_lanes)
     {
         // lane = particle; (64-particle block, beam segment) work items; see k_rays_pl
         a.grid = h->clr;
@@ -424,7 +427,6 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             h->lw_cap = need;
         }
         a.lw = h->lw;
-        static const int order_mode = getenv("SLAM_PL_ORDER") ? atoi(getenv("SLAM_PL_ORDER")) : 3;
         static const int order_bits = getenv("SLAM_PL_ORDER_BITS") ? atoi(getenv("SLAM_PL_ORDER_BITS")) : 32;
         if (order_mode > 0)
         {
@@ -443,7 +445,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 h->osort_tmp_bytes = bytes;
             }
             hipLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x,
-                               h->y, h->th, order_mode, order_bits, h->okeys, h->oident);
+                               h->y, h->th, order_mode, order_bits, h->okeys, h->oident, h->stats);
             size_t bytes = h->osort_tmp_bytes;
             HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, order_bits,
                                              h->stream));
@@ -521,6 +523,26 @@ int do_prefix(slam_mcl* h, const slamk::StateView& view)
     }
     const int L = (int)h->lvl_n.size();
     const double* in = lin;  // nullptr: level 0 reads the weight column of the view
+    if (L >= 3 && L <= 8 && h->lvl_n[1] <= 65536)
+    {
+        // the small upper levels in one launch (3 launches for 100k particles instead of 5)
+        hipLaunchKernelGGL(slamk::k_scan_chunks, dim3((unsigned)cdiv(cdiv(h->lvl_n[0], 64), 4)), dim3(256), 0, h->stream, in, view,
+                           h->lvl_n[0], h->lvl_s[0], h->lvl_tot[0]);
+        slamk::UpperLevels u;
+        u.L = L;
+        for (int l = 0; l < L; ++l)
+        {
+            u.n[l] = h->lvl_n[l];
+            u.s[l] = h->lvl_s[l];
+            u.tot[l] = h->lvl_tot[l];
+            u.P[l] = h->lvl_P[l];
+        }
+        hipLaunchKernelGGL(slamk::k_scan_upper, dim3(1), dim3(1024), 0, h->stream, u);
+        hipLaunchKernelGGL(slamk::k_downsweep, dim3((unsigned)cdiv(h->lvl_n[0], 256)), dim3(256), 0, h->stream, h->lvl_s[0],
+                           h->lvl_P[1], h->lvl_n[0], h->lvl_P[0]);
+        HIPCHK(hipGetLastError());
+        return SLAM_OK;
+    }
     for (int l = 0; l < L; ++l)
     {
         const int64_t nl = h->lvl_n[l];
@@ -579,6 +601,9 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
         s.step = h->resample_step;
         s.resampler = h->prm.resampler;
         s.idx = h->idx;
+        s.view = view;
+        s.keys = h->prm.sort == SLAM_SORT_FULL ? h->keys : nullptr;
+        s.slots = h->slots;
         hipLaunchKernelGGL(slamk::k_select, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, s);
         HIPCHK(hipGetLastError());
     }
@@ -586,8 +611,6 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
     if (h->prm.sort == SLAM_SORT_FULL)
     {
         slam_mcl::Span span(h, G_SORT);
-        hipLaunchKernelGGL(slamk::k_sort_keys, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, view, h->idx, n,
-                           h->keys, h->slots);
         size_t bytes = h->sort_tmp_bytes;
         HIPCHK(rocprim::radix_sort_pairs_desc(h->sort_tmp, bytes, h->keys, h->keys2, h->slots, h->perm, (size_t)n, 0, 64,
                                               h->stream));
