@@ -196,12 +196,14 @@ int slam_mcl_shard_resample_split(slam_mcl* h, const double* gathered_poses_dev,
  *   2. the caller tells every owner which of its canvases are wanted, the owners pack them with
  *      slam_mcl_pack_maps (out_dev[c] = canvas local_idx_dev[c], map_stride bytes each) and the
  *      packed canvases travel (all-to-all over RCCL, slam_amd/dist.py);
- *   3. slam_mcl_shard_clone_maps: canvas of local slot k = pool_dev[pos_dev[k]] (map_stride bytes
- *      each), which completes the resample.
+ *   3. slam_mcl_shard_clone_maps: canvas of local slot k = pool_dev[pos_dev[k]] (pool_count canvases of
+ *      map_stride bytes), which completes the resample.
+ * The index arrays live on the device, so the library cannot check them before launching: an entry
+ * out of range is skipped by the kernels and the next synchronising call returns SLAM_ERR_ARG.
  * predict / update_weights before step 3 would see stale canvases; update_weights refuses. */
 int slam_mcl_shard_select(slam_mcl* h, const double* gathered_state_dev, int32_t n_shards);
 int slam_mcl_pack_maps(slam_mcl* h, const int32_t* local_idx_dev, int64_t count, uint8_t* out_dev);
-int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, const int32_t* pos_dev);
+int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, int64_t pool_count, const int32_t* pos_dev);
 /* The same exchange for SLAM_MAPS_TILED handles.  slam_mcl_pack_maps / slam_mcl_shard_clone_maps work
  * on them as well (canvases then travel dense; blank tiles stay shared on arrival), but a tiled
  * shard normally holds far more canvases than would fit dense, so steps 2 and 3 have a sparse
@@ -211,7 +213,7 @@ int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, const int32_
  *   2'. slam_mcl_pack_tiles_count (how many tiles the request needs: the caller sizes the buffers),
  *       then slam_mcl_pack_tiles with the same arguments: tabs_out_dev[c] = table of canvas
  *       local_idx_dev[c], tiles_out_dev = the n_tiles payload tiles;
- *   3'. slam_mcl_shard_import_tiles: tabs_dev/tiles_dev = the received tables and tiles of all owners
+ *   3'. slam_mcl_shard_import_tiles: tabs_dev/tiles_dev = the n_tabs received tables and n_tiles tiles of all owners
  *       (the caller has shifted each owner's table entries by the position of that owner's first tile
  *       in tiles_dev); canvas of local slot k = table pos_dev[k].  Slots cloned from one source share
  *       its tiles until they write.  SLAM_ERR_NOMEM if the pool is smaller than n_tiles.
@@ -222,8 +224,8 @@ int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, const int32_
 int slam_mcl_pack_tiles_count(slam_mcl* h, const int32_t* local_idx_dev, int64_t count, int64_t* n_tiles_out);
 int slam_mcl_pack_tiles(slam_mcl* h, const int32_t* local_idx_dev, int64_t count, int32_t* tabs_out_dev,
                         uint8_t* tiles_out_dev, int64_t n_tiles);
-int slam_mcl_shard_import_tiles(slam_mcl* h, const int32_t* tabs_dev, const uint8_t* tiles_dev, int64_t n_tiles,
-                                const int32_t* pos_dev);
+int slam_mcl_shard_import_tiles(slam_mcl* h, const int32_t* tabs_dev, int64_t n_tabs, const uint8_t* tiles_dev,
+                                int64_t n_tiles, const int32_t* pos_dev);
 typedef struct slam_mcl_device_maps
 {
     uint8_t* maps_dev;       /* n_particles canvases, map_stride bytes apart (rows*cols valid bytes each); NULL if tiled */

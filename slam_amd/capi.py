@@ -91,10 +91,10 @@ SYMBOLS = {
     "slam_mcl_shard_select": (ctypes.c_int, [_P, _P, _I32]),
     "slam_mcl_shard_resample_split": (ctypes.c_int, [_P, _P, _P, _I32]),
     "slam_mcl_pack_maps": (ctypes.c_int, [_P, _P, _I64, _P]),
-    "slam_mcl_shard_clone_maps": (ctypes.c_int, [_P, _P, _P]),
+    "slam_mcl_shard_clone_maps": (ctypes.c_int, [_P, _P, _I64, _P]),
     "slam_mcl_pack_tiles_count": (ctypes.c_int, [_P, _P, _I64, _P]),
     "slam_mcl_pack_tiles": (ctypes.c_int, [_P, _P, _I64, _P, _P, _I64]),
-    "slam_mcl_shard_import_tiles": (ctypes.c_int, [_P, _P, _P, _I64, _P]),
+    "slam_mcl_shard_import_tiles": (ctypes.c_int, [_P, _P, _I64, _P, _I64, _P]),
     "slam_mcl_device_maps_get": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_tile_stats": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_poses": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64]),

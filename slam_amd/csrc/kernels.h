@@ -893,10 +893,16 @@ __global__ void __launch_bounds__(256) k_gather(StateView view, const int32_t* i
 
 // slam/mcl.cpp:147-155: deep copy of each selected particle's map.  grid = (particles, chunks).
 // Also packs maps for the sharded exchange (dst slot p <- src map src[p]).
+// An index outside [0, n_src) (a caller's device array) is skipped and reported through *bad.
 __global__ void __launch_bounds__(256) k_clone_maps(const uint8_t* maps, uint8_t* maps2, const int32_t* src,
-                                                    size_t stride)
+                                                    size_t stride, int64_t n_src, int* bad)
 {
     const size_t p = blockIdx.x;
+    if ((uint64_t)(int64_t)src[p] >= (uint64_t)n_src)
+    {
+        *bad = 1;
+        return;
+    }
     const uint4* from = reinterpret_cast<const uint4*>(maps + stride * (size_t)src[p]);
     uint4* to = reinterpret_cast<uint4*>(maps2 + stride * p);
     const size_t n16 = stride / 16;
@@ -1109,14 +1115,17 @@ __global__ void __launch_bounds__(256) k_untile(const uint8_t* pool, const int32
 // k_pack_mark: one thread per (requested canvas, table entry); the first thread to stamp a tile with
 // this pack's number gives it the next payload position (one atomic per wavefront on the counter).
 __global__ void __launch_bounds__(256) k_pack_mark(const int32_t* tab, int T, const int32_t* local_idx, int64_t total, int gen,
-                                                   int* stamp, int32_t* slot, int32_t* list, int* counter)
+                                                   int* stamp, int32_t* slot, int32_t* list, int* counter, int64_t n_src, int* bad)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int id = 0;
     if (k < total)
     {
         const int64_t c = k / T;
-        id = tab[(size_t)local_idx[c] * T + (size_t)(k - c * T)] & ~TILE_OWN;
+        if ((uint64_t)(int64_t)local_idx[c] < (uint64_t)n_src)
+            id = tab[(size_t)local_idx[c] * T + (size_t)(k - c * T)] & ~TILE_OWN;
+        else
+            *bad = 1;  // a canvas that does not exist travels as a blank one
     }
     const bool fresh = id != 0 && atomicExch(&stamp[id], gen) != gen;
     const uint64_t vote = __ballot(fresh);
@@ -1134,12 +1143,13 @@ __global__ void __launch_bounds__(256) k_pack_mark(const int32_t* tab, int T, co
 }
 
 __global__ void __launch_bounds__(256) k_pack_tabs(const int32_t* tab, int T, const int32_t* local_idx, int64_t total,
-                                                   const int32_t* slot, int32_t* out)
+                                                   const int32_t* slot, int32_t* out, int64_t n_src)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total) return;
     const int64_t c = k / T;
-    const int id = tab[(size_t)local_idx[c] * T + (size_t)(k - c * T)] & ~TILE_OWN;
+    const bool ok = (uint64_t)(int64_t)local_idx[c] < (uint64_t)n_src;  // (k_pack_mark has reported it)
+    const int id = ok ? tab[(size_t)local_idx[c] * T + (size_t)(k - c * T)] & ~TILE_OWN : 0;
     out[k] = id ? slot[id] + 1 : 0;
 }
 
@@ -1154,15 +1164,16 @@ __global__ void __launch_bounds__(256) k_tiles_copy(const uint8_t* from, const i
 
 // slot p takes row pos[p] of the received tables; entry e > 0 = payload tile e - 1, now pool tile ids[e - 1]
 __global__ void __launch_bounds__(256) k_import_tabs(const int32_t* tabs, const int32_t* pos, int T, int64_t total, int n_tiles,
-                                                     const int32_t* ids, int32_t* tab, int* ctrl)
+                                                     const int32_t* ids, int32_t* tab, int64_t n_tabs, int* bad)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total) return;
     const int64_t p = k / T;
-    const int e = tabs[(size_t)pos[p] * T + (size_t)(k - p * T)];
+    const bool row_ok = (uint64_t)(int64_t)pos[p] < (uint64_t)n_tabs;
+    const int e = row_ok ? tabs[(size_t)pos[p] * T + (size_t)(k - p * T)] : -1;
     if (e < 0 || e > n_tiles)
     {
-        ctrl[2] = 1;  // a table that names a tile outside the payload
+        *bad = 1;  // a slot without a table, or a table that names a tile outside the payload
         tab[k] = 0;
         return;
     }
@@ -1172,10 +1183,15 @@ __global__ void __launch_bounds__(256) k_import_tabs(const int32_t* tabs, const 
 // Sharded exchange of tiled canvases travels as dense canvases (slam_amd/dist.py): export of the
 // requested particles, grid (cells / 256, count) ...
 __global__ void __launch_bounds__(256) k_untile_many(const uint8_t* pool, const int32_t* tab, int T, int tcols, int rows, int cols,
-                                                     const int32_t* local_idx, size_t stride, uint8_t* out)
+                                                     const int32_t* local_idx, size_t stride, uint8_t* out, int64_t n_src, int* bad)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (int64_t)rows * cols) return;
+    if ((uint64_t)(int64_t)local_idx[blockIdx.y] >= (uint64_t)n_src)
+    {
+        *bad = 1;
+        return;
+    }
     const int32_t* tab_p = tab + (size_t)local_idx[blockIdx.y] * T;
     const int i = (int)(k / cols), j = (int)(k - (int64_t)i * cols);
     const int id = tab_p[(i >> TILE_SHIFT) * tcols + (j >> TILE_SHIFT)] & ~TILE_OWN;
@@ -1187,11 +1203,20 @@ __global__ void __launch_bounds__(256) k_untile_many(const uint8_t* pool, const 
 // the census that follows).
 __global__ void __launch_bounds__(256) k_tile_import_many(const uint8_t* dense_pool, const int32_t* pos, size_t stride, int rows,
                                                           int cols, int32_t* tab, int T, int tcols, uint8_t* pool,
-                                                          const int32_t* freelist, int* ctrl)
+                                                          const int32_t* freelist, int* ctrl, int64_t n_pool, int* bad)
 {
     __shared__ int nid_s, any_s;
     const int t = blockIdx.x;
     const size_t p = blockIdx.y;
+    if ((uint64_t)(int64_t)pos[p] >= (uint64_t)n_pool)
+    {  // whole workgroup: the slot keeps a blank canvas
+        if (threadIdx.x == 0)
+        {
+            tab[p * T + t] = 0;
+            *bad = 1;
+        }
+        return;
+    }
     const uint8_t* dense = dense_pool + stride * (size_t)pos[p];
     const int ti = t / tcols, tj = t - ti * tcols;
     if (threadIdx.x == 0) any_s = 0;

@@ -94,6 +94,8 @@ struct slam_mcl
     int tile_gen = 0;  // number of the last collection: a tile is referenced iff its mark equals it
     int *pack_stamp = nullptr, *pack_ctr = nullptr;  // sparse canvas exchange: per tile the number of the pack that listed it
     int32_t* pack_slot = nullptr;                    // ... and its position in that pack's payload
+    int* dev_bad = nullptr;  // set by a kernel that met an out-of-range entry in a caller's device index array
+    bool bad_armed = false;  // an entry point that takes such an array has run since the last check
     int pack_gen = 0;
     int64_t pack_tiles = -1, pack_count = -1;        // what the last slam_mcl_pack_tiles_count found, for whom
     const int32_t* pack_idx = nullptr;
@@ -179,6 +181,18 @@ int finish(slam_mcl* h)
 {
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->bad_armed)
+    {
+        int bad = 0;
+        HIPCHK(hipMemcpy(&bad, h->dev_bad, sizeof(int), hipMemcpyDeviceToHost));
+        h->bad_armed = false;
+        if (bad)
+        {
+            HIPCHK(hipMemset(h->dev_bad, 0, sizeof(int)));
+            return fail(SLAM_ERR_ARG, "a device index array (local_idx_dev / pos_dev / tabs_dev) held an entry out of range: "
+                                      "those entries were skipped, the canvases are incomplete");
+        }
+    }
     if (h->tiled)
     {
         int ctrl[3];
@@ -561,11 +575,12 @@ int do_prefix(slam_mcl* h, const slamk::StateView& view)
     return SLAM_OK;
 }
 
-void launch_clone(slam_mcl* h, const uint8_t* from, uint8_t* to, const int32_t* src, int64_t count)
+// n_src: canvases behind `from` (entries of src outside it are skipped and reported by finish())
+void launch_clone(slam_mcl* h, const uint8_t* from, uint8_t* to, const int32_t* src, int64_t count, int64_t n_src)
 {
     const unsigned chunks = (unsigned)std::min<size_t>(cdiv((int64_t)(h->map_stride / 16), 256), 64);
     hipLaunchKernelGGL(slamk::k_clone_maps, dim3((unsigned)count, chunks), dim3(256), 0, h->stream, from, to, src,
-                       h->map_stride);
+                       h->map_stride, n_src, h->dev_bad);
 }
 
 // `gathered`: packed states of all shards ([n_shards][4][n]); nullptr = this handle alone.
@@ -635,7 +650,7 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
     else if (h->prm.mode == SLAM_MODE_SLAM && clone_local)
     {
         slam_mcl::Span span(h, G_CLONE);
-        launch_clone(h, h->maps, h->maps2, h->src, n);
+        launch_clone(h, h->maps, h->maps2, h->src, n, n);
         HIPCHK(hipGetLastError());
         std::swap(h->maps, h->maps2);
     }
@@ -670,7 +685,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
                     h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
                     h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->wlin, h->wmax,
                     h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_who, h->tile_shared, h->tile_ctrl, h->tile_dense, h->tile_sector,
-                    h->tile_wl_p, h->tile_wl_t, h->pack_stamp, h->pack_ctr, h->pack_slot};
+                    h->tile_wl_p, h->tile_wl_t, h->pack_stamp, h->pack_ctr, h->pack_slot, h->dev_bad};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (int k = 0; k < slam_mcl::SCAN_RING; ++k)
@@ -728,6 +743,8 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
     TRY(dev_alloc(&h->state2, 4 * n));
     if (!rc) h->bind();
     TRY(dev_alloc(&h->idx, n));
+    TRY(dev_alloc(&h->dev_bad, 1));
+    if (!rc && hipMemsetAsync(h->dev_bad, 0, sizeof(int), h->stream) != hipSuccess) rc = fail(SLAM_ERR_HIP, "memset");
     TRY(dev_alloc(&h->perm, n));
     TRY(dev_alloc(&h->slots, n));
     TRY(dev_alloc(&h->src, n));
@@ -1134,26 +1151,28 @@ SLAM_API int slam_mcl_pack_maps(slam_mcl* h, const int32_t* local_idx_dev, int64
             const int64_t cn = std::min<int64_t>(65535, count - c0);
             hipLaunchKernelGGL(slamk::k_untile_many, dim3((unsigned)cdiv(cells, 256), (unsigned)cn), dim3(256), 0, h->stream,
                                h->tile_pool, h->tile_tab, h->tile_T, h->tile_tc, h->rows, h->cols, local_idx_dev + c0,
-                               h->map_stride, out_dev + h->map_stride * (size_t)c0);
+                               h->map_stride, out_dev + h->map_stride * (size_t)c0, h->n, h->dev_bad);
         }
         HIPCHK(hipGetLastError());
     }
     else if (count > 0)
     {
         slam_mcl::Span span(h, G_CLONE);
-        launch_clone(h, h->maps, out_dev, local_idx_dev, count);
+        launch_clone(h, h->maps, out_dev, local_idx_dev, count, h->n);
         HIPCHK(hipGetLastError());
     }
+    h->bad_armed = true;
     return maybe_finish(h);
 }
 
-SLAM_API int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, const int32_t* pos_dev)
+SLAM_API int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, int64_t pool_count, const int32_t* pos_dev)
 {
     int rc = check_handle(h);
     if (rc) return rc;
     if (h->prm.mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_STATE, "shard_clone_maps: SLAM mode only");
     if (!h->maps_pending) return fail(SLAM_ERR_STATE, "shard_clone_maps: no slam_mcl_shard_select pending");
-    if (!pool_dev || !pos_dev) return fail(SLAM_ERR_ARG, "shard_clone_maps: null pointer");
+    if (!pool_dev || !pos_dev || pool_count < 1) return fail(SLAM_ERR_ARG, "shard_clone_maps: null pointer or empty pool");
+    h->bad_armed = true;
     if (h->tiled)
     {
         // every tile of the old canvases becomes free, then each slot imports its received canvas (blank
@@ -1166,7 +1185,7 @@ SLAM_API int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, con
             const int64_t pn = std::min<int64_t>(65535, h->n - p0);
             hipLaunchKernelGGL(slamk::k_tile_import_many, dim3((unsigned)h->tile_T, (unsigned)pn), dim3(256), 0, h->stream, pool_dev,
                                pos_dev + p0, h->map_stride, h->rows, h->cols, h->tile_tab + (size_t)p0 * h->tile_T, h->tile_T,
-                               h->tile_tc, h->tile_pool, h->tile_free, h->tile_ctrl);
+                               h->tile_tc, h->tile_pool, h->tile_free, h->tile_ctrl, pool_count, h->dev_bad);
         }
         HIPCHK(hipGetLastError());
         if ((rc = tile_collect(h, nullptr))) return rc;
@@ -1175,7 +1194,7 @@ SLAM_API int slam_mcl_shard_clone_maps(slam_mcl* h, const uint8_t* pool_dev, con
     }
     {
         slam_mcl::Span span(h, G_CLONE);
-        launch_clone(h, pool_dev, h->maps2, pos_dev, h->n);
+        launch_clone(h, pool_dev, h->maps2, pos_dev, h->n, pool_count);
         HIPCHK(hipGetLastError());
     }
     std::swap(h->maps, h->maps2);
@@ -1205,11 +1224,12 @@ SLAM_API int slam_mcl_pack_tiles_count(slam_mcl* h, const int32_t* local_idx_dev
         const int64_t total = count * h->tile_T;
         HIPCHK(hipMemsetAsync(h->pack_ctr, 0, sizeof(int), h->stream));
         hipLaunchKernelGGL(slamk::k_pack_mark, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, h->tile_T,
-                           local_idx_dev, total, ++h->pack_gen, h->pack_stamp, h->pack_slot, h->tile_wl_t, h->pack_ctr);
+                           local_idx_dev, total, ++h->pack_gen, h->pack_stamp, h->pack_slot, h->tile_wl_t, h->pack_ctr, h->n, h->dev_bad);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&found, h->pack_ctr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    h->bad_armed = true;
     h->pack_tiles = *n_tiles_out = found;
     h->pack_count = count;
     h->pack_idx = local_idx_dev;
@@ -1231,7 +1251,7 @@ SLAM_API int slam_mcl_pack_tiles(slam_mcl* h, const int32_t* local_idx_dev, int6
         slam_mcl::Span span(h, G_CLONE);
         const int64_t total = count * h->tile_T;
         hipLaunchKernelGGL(slamk::k_pack_tabs, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, h->tile_T,
-                           local_idx_dev, total, h->pack_slot, tabs_out_dev);
+                           local_idx_dev, total, h->pack_slot, tabs_out_dev, h->n);
         if (n_tiles > 0)
             hipLaunchKernelGGL(slamk::k_tiles_copy, dim3((unsigned)n_tiles), dim3(256), 0, h->stream, h->tile_pool, h->tile_wl_t,
                                tiles_out_dev, (const int32_t*)nullptr);
@@ -1240,15 +1260,17 @@ SLAM_API int slam_mcl_pack_tiles(slam_mcl* h, const int32_t* local_idx_dev, int6
     return maybe_finish(h);
 }
 
-SLAM_API int slam_mcl_shard_import_tiles(slam_mcl* h, const int32_t* tabs_dev, const uint8_t* tiles_dev, int64_t n_tiles,
-                                         const int32_t* pos_dev)
+SLAM_API int slam_mcl_shard_import_tiles(slam_mcl* h, const int32_t* tabs_dev, int64_t n_tabs, const uint8_t* tiles_dev,
+                                         int64_t n_tiles, const int32_t* pos_dev)
 {
     int rc = check_handle(h);
     if (rc) return rc;
     if (h->prm.mode != SLAM_MODE_SLAM || !h->tiled)
         return fail(SLAM_ERR_STATE, "shard_import_tiles: SLAM mode with tiled canvases only");
     if (!h->maps_pending) return fail(SLAM_ERR_STATE, "shard_import_tiles: no slam_mcl_shard_select pending");
-    if (!tabs_dev || !pos_dev || n_tiles < 0 || (n_tiles > 0 && !tiles_dev)) return fail(SLAM_ERR_ARG, "shard_import_tiles: null pointer");
+    if (!tabs_dev || !pos_dev || n_tabs < 1 || n_tiles < 0 || (n_tiles > 0 && !tiles_dev))
+        return fail(SLAM_ERR_ARG, "shard_import_tiles: null pointer or no tables");
+    h->bad_armed = true;
     if (n_tiles > h->tile_cap - 1)
         return fail(SLAM_ERR_NOMEM, "shard_import_tiles: " + std::to_string(n_tiles) + " tiles arrive, the pool holds " +
                                         std::to_string(h->tile_cap - 1) + ": recreate the handle with a larger tile_pool_tiles");
@@ -1262,7 +1284,7 @@ SLAM_API int slam_mcl_shard_import_tiles(slam_mcl* h, const int32_t* tabs_dev, c
                            h->tile_pool, h->tile_free);
     const int64_t total = (int64_t)h->n * h->tile_T;
     hipLaunchKernelGGL(slamk::k_import_tabs, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, tabs_dev, pos_dev, h->tile_T,
-                       total, (int)n_tiles, h->tile_free, h->tile_tab, h->tile_ctrl);
+                       total, (int)n_tiles, h->tile_free, h->tile_tab, n_tabs, h->dev_bad);
     HIPCHK(hipGetLastError());
     // the free list is rebuilt by the census, which reads the tables just written
     if ((rc = tile_collect(h, nullptr))) return rc;

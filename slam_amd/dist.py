@@ -73,7 +73,7 @@ class HipShard:
 
     def clone_maps(self, pool, pos):
         pos32 = pos.to(torch.int32).contiguous()
-        self.f.shard_clone_maps(pool.data_ptr(), pos32.data_ptr())
+        self.f.shard_clone_maps(pool.contiguous().data_ptr(), pool.shape[0], pos32.data_ptr())
 
     def pack_tiles(self, local_idx):
         """(tables (count, tiles_per_canvas) int32, tiles (n_tiles, 4096) uint8) of the requested canvases."""
@@ -86,7 +86,8 @@ class HipShard:
 
     def import_tiles(self, tabs, tiles, pos):
         pos32 = pos.to(torch.int32).contiguous()
-        self.f.shard_import_tiles(tabs.contiguous().data_ptr(), tiles.contiguous().data_ptr(), tiles.shape[0], pos32.data_ptr())
+        self.f.shard_import_tiles(tabs.contiguous().data_ptr(), tabs.shape[0], tiles.contiguous().data_ptr(), tiles.shape[0],
+                                  pos32.data_ptr())
 
 
 class ShardedFilter:

@@ -151,9 +151,9 @@ class Filter:
         check(self.lib.slam_mcl_pack_maps(self._h, ctypes.c_void_p(int(local_idx_ptr)), count,
                                           ctypes.c_void_p(int(out_ptr))), self.lib)
 
-    def shard_clone_maps(self, pool_ptr, pos_ptr):
-        check(self.lib.slam_mcl_shard_clone_maps(self._h, ctypes.c_void_p(int(pool_ptr)), ctypes.c_void_p(int(pos_ptr))),
-              self.lib)
+    def shard_clone_maps(self, pool_ptr, pool_count, pos_ptr):
+        check(self.lib.slam_mcl_shard_clone_maps(self._h, ctypes.c_void_p(int(pool_ptr)), pool_count,
+                                                 ctypes.c_void_p(int(pos_ptr))), self.lib)
 
     def pack_tiles_count(self, local_idx_ptr, count):
         """Tiled canvases, sparse exchange: how many distinct tiles the `count` requested canvases name."""
@@ -165,9 +165,9 @@ class Filter:
         check(self.lib.slam_mcl_pack_tiles(self._h, ctypes.c_void_p(int(local_idx_ptr)), count, ctypes.c_void_p(int(tabs_ptr)),
                                            ctypes.c_void_p(int(tiles_ptr)), n_tiles), self.lib)
 
-    def shard_import_tiles(self, tabs_ptr, tiles_ptr, n_tiles, pos_ptr):
-        check(self.lib.slam_mcl_shard_import_tiles(self._h, ctypes.c_void_p(int(tabs_ptr)), ctypes.c_void_p(int(tiles_ptr)),
-                                                   n_tiles, ctypes.c_void_p(int(pos_ptr))), self.lib)
+    def shard_import_tiles(self, tabs_ptr, n_tabs, tiles_ptr, n_tiles, pos_ptr):
+        check(self.lib.slam_mcl_shard_import_tiles(self._h, ctypes.c_void_p(int(tabs_ptr)), n_tabs,
+                                                   ctypes.c_void_p(int(tiles_ptr)), n_tiles, ctypes.c_void_p(int(pos_ptr))), self.lib)
 
     def device_maps(self):
         dm = capi.DeviceMaps()

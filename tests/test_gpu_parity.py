@@ -471,6 +471,38 @@ def test_tiled_pool_exhaustion_is_reported(sa):
     f.close()
 
 
+@pytest.mark.parametrize("storage", ["dense", "tiled"])
+def test_device_index_arrays_are_range_checked(sa, storage):
+    """local_idx_dev / pos_dev live on the device: an entry out of range must not reach memory; it is
+    skipped and reported by the call (synchronous handles) as an error."""
+    import torch
+
+    from slam_amd.dist import HipShard
+
+    st = {"dense": sa.capi.MAPS_DENSE, "tiled": sa.capi.MAPS_TILED}[storage]
+    n, rows, cols = 8, 70, 90
+    b = HipShard(n, rows, cols, 0, 1, 0, 5, mode=sa.capi.MODE_SLAM, map_storage=st)
+    good = b.pack_maps(torch.arange(n, device="cuda"))
+    assert good.shape[0] == n and int(good[:, :rows * cols].min()) == 128
+    with pytest.raises(RuntimeError, match="out of range"):
+        b.pack_maps(torch.tensor([0, n, 1], device="cuda"))
+    with pytest.raises(RuntimeError, match="out of range"):
+        b.pack_maps(torch.tensor([-1], device="cuda"))
+    b.pack_maps(torch.tensor([n - 1], device="cuda"))   # the flag was cleared by the report
+    if storage == "tiled":
+        with pytest.raises(RuntimeError, match="out of range"):
+            b.pack_tiles(torch.tensor([n + 3], device="cuda"))
+    # the import side: a slot that points past the received pool
+    ang, dist = np.linspace(-3, 3, 12), np.full(12, 20.0)
+    b.update_weights(ang, dist, 5.0, 50.0, OFFSET)
+    b.shard_select(b.packed_state().clone(), 1)
+    pos = torch.zeros(n, dtype=torch.int64, device="cuda")
+    pos[3] = 2
+    with pytest.raises(RuntimeError, match="out of range"):
+        b.clone_maps(good[:2].contiguous(), pos)
+    b.f.close()
+
+
 @pytest.mark.parametrize("order", ["blocked", "reference"])
 def test_localization_loop(sa, order):
     rng = np.random.default_rng(99)
