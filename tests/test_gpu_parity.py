@@ -701,6 +701,49 @@ def test_sharded_filter_matches_single_handle(sa, shards, split):
     assert_bits(sf.b.f.poses()[0], ox[idx], "ShardedFilter world=1")
 
 
+def test_eight_shards_of_the_bench_size(sa):
+    """The 8-GPU bench configuration (8 shards x 100 000 particles, floor plan), its shards emulated on
+    one device: same selection, poses and weights as ONE handle of 800 000 particles."""
+    import torch
+
+    from slam_amd.dist import HipShard
+
+    rng = np.random.default_rng(8)
+    shards, n_loc, B, seed = 8, 100_000, 24, 0x5EED0001
+    N = shards * n_loc
+    free = orc.load_map("floor_plan")
+    g = (free * 255).astype(np.uint8)
+    rows, cols = g.shape
+    true = [520.0, 280.0, 0.4]
+    ang, dist = orc.make_scan(free, true, OFFSET, B)
+    x, y, th = cloud(rng, N, true[0], true[1], sxy=25.0, sth=0.2, th0=true[2])
+    single = sa.Filter(N, rows, cols, seed=seed, sort=sa.capi.SORT_NONE)
+    single.set_map(g)
+    single.set_poses(x, y, th)
+    backs = [HipShard(n_loc, rows, cols, r, shards, 0, seed) for r in range(shards)]
+    for r, b in enumerate(backs):
+        b.set_map(g)
+        b.f.set_poses(x[r * n_loc:(r + 1) * n_loc], y[r * n_loc:(r + 1) * n_loc], th[r * n_loc:(r + 1) * n_loc])
+    for step in range(2):
+        single.predict(ODOM, ALPHAS)
+        single.update(ang, dist, 5.0, 500.0, OFFSET)
+        for b in backs:
+            b.predict(ODOM, ALPHAS)
+            b.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+        gathered = torch.cat([b.packed_state() for b in backs])
+        torch.cuda.synchronize()
+        for b in backs:
+            b.shard_resample(gathered, shards)
+        assert np.array_equal(np.concatenate([b.f.last_indices() for b in backs]), single.last_indices())
+        for q in range(3):
+            assert_bits(np.concatenate([b.f.poses()[q] for b in backs]), single.poses()[q], f"pose column {q}, step {step}")
+        assert_bits(np.concatenate([b.f.weights() for b in backs]), single.weights(), "weights")
+    assert len(np.unique(single.last_indices())) > 1000
+    single.close()
+    for b in backs:
+        b.f.close()
+
+
 @pytest.mark.parametrize("shards,storage", [(2, "dense"), (4, "dense"), (2, "tiled"), (4, "tiled"), (2, "tiles"), (4, "tiles")])
 def test_sharded_slam_mode_matches_single_handle(sa, shards, storage):
     """SLAM-mode shards: select, canvas exchange (emulated here on one device: what the two small
