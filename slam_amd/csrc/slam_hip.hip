@@ -244,6 +244,26 @@ void build_luts(uint8_t* t)
     }
 }
 
+// Tuning knobs of the particle-lane weighting pass, read once from the environment (experiments and
+// tools/; the defaults are what the measurements in DESIGN.md chose).
+struct Tuning
+{
+    int order_mode;  // SLAM_PL_ORDER: 0 = no pose-coherent order, else kind | (tile_shift + 1) << 4 | heading_bits << 8
+    int order_bits;  // SLAM_PL_ORDER_BITS: bits of the order key that are sorted
+    int seg_beams;   // SLAM_PL_SEG: beams per work item (0 = chosen from the launch size)
+    int waves;       // SLAM_PL_WAVES: wavefronts per SIMD the ray kernel is compiled for (4, 5, 6 or 8)
+};
+const Tuning& tuning()
+{
+    auto env_int = [](const char* name, int dflt) {
+        const char* v = getenv(name);
+        return v ? atoi(v) : dflt;
+    };
+    static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
+                             env_int("SLAM_PL_WAVES", 5)};
+    return t;
+}
+
 int check_handle(slam_mcl* h)
 {
     if (!h) return fail(SLAM_ERR_ARG, "null handle");
@@ -362,7 +382,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.hit_cell = h->record_hits ? h->hit_cell : nullptr;
     a.stats = h->stats;
     a.luts = h->luts;
-    static const int order_mode = getenv("SLAM_PL_ORDER") ? atoi(getenv("SLAM_PL_ORDER")) : 3;
+    const int order_mode = tuning().order_mode;
     const bool particle_lanes = !slam_mode && (h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES ||
                                                (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096));
     if (!(particle_lanes && order_mode > 0 && h->n >= 3))  // k_order_keys zeroes the counters itself
@@ -441,7 +461,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             h->lw_cap = need;
         }
         a.lw = h->lw;
-        static const int order_bits = getenv("SLAM_PL_ORDER_BITS") ? atoi(getenv("SLAM_PL_ORDER_BITS")) : 32;
+        const int order_bits = tuning().order_bits;
         if (order_mode > 0)
         {
             if (!h->okeys)
@@ -474,11 +494,11 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             if (want < 1) want = 1;
             if (want > B) want = B;
             a.seg_beams = (int)cdiv(B, want);
-            static const int seg_env = getenv("SLAM_PL_SEG") ? atoi(getenv("SLAM_PL_SEG")) : 0;
+            const int seg_env = tuning().seg_beams;
             if (seg_env > 0) a.seg_beams = seg_env < B ? seg_env : B;
             a.nseg = (int)cdiv(B, a.seg_beams);
             const dim3 grid((unsigned)cdiv(a.npblocks * a.nseg, 4));
-            static const int pl_waves = getenv("SLAM_PL_WAVES") ? atoi(getenv("SLAM_PL_WAVES")) : 5;
+            const int pl_waves = tuning().waves;
             if (pl_waves >= 8)
                 hipLaunchKernelGGL(slamk::k_rays_pl<8>, grid, dim3(256), 0, h->stream, a);
             else if (pl_waves >= 6)
