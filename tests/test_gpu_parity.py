@@ -461,6 +461,33 @@ def test_tiled_canvases_reuse_collected_tiles(sa):
     dense.close(), tiled.close()
 
 
+def test_tiled_canvases_larger_than_the_lds_table(sa):
+    """Canvases of more than 3072 tiles: the tile table no longer fits the 48 KiB of LDS the walk stages
+    it in and is read from memory instead.  Same weights, selection and canvases as dense storage."""
+    rng = np.random.default_rng(77)
+    N, B, rows, cols, zmax, seed = 6, 40, 3600, 3700, 300.0, 0x7AB1E
+    free = orc.load_map("map")
+    ang, dist = orc.make_scan(free, [400.0, 400.0, np.pi / 90], OFFSET, B, max_dist=zmax)
+    assert ((rows + 63) // 64) * ((cols + 63) // 64) > 3072
+    x, y, th = cloud(rng, N, cols / 2, rows / 2, sxy=30.0, sth=0.4, th0=np.pi / 2)
+    x[0], y[0] = 10.0, rows - 5.0   # a corner of the canvas
+    fs = [sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=seed, map_storage=st)
+          for st in (sa.capi.MAPS_DENSE, sa.capi.MAPS_TILED)]
+    for f in fs:
+        f.set_poses(x, y, th)
+    for step in range(3):
+        for f in fs:
+            f.predict([0.05, 4.0, -0.02], ALPHAS)
+            f.update(ang, dist, 5.0, zmax, OFFSET)
+        assert np.array_equal(fs[0].last_indices(), fs[1].last_indices())
+        assert_bits(fs[1].weights(), fs[0].weights(), f"weights, step {step}")
+        for p in range(N):
+            assert np.array_equal(fs[1].map_of(p), fs[0].map_of(p)), f"canvas {p}, step {step}"
+    assert (fs[0].map_of(0) != 128).any()
+    for f in fs:
+        f.close()
+
+
 def test_tiled_pool_exhaustion_is_reported(sa):
     N, B, rows, cols = 32, 90, 400, 400
     free = orc.load_map("map")
