@@ -201,6 +201,44 @@ def test_weights_hostile_poses(sa, N, mapname, zmax):
         f.close()
 
 
+@pytest.mark.parametrize("N,B", [(1, 1), (1, 129), (2, 64), (65, 65)])
+def test_smallest_filters_both_modes(sa, N, B):
+    """One or two particles, one beam, beam counts around the wavefront size: full steps in both modes."""
+    rng = np.random.default_rng(N * 1000 + B)
+    free = orc.load_map("map")
+    g = (free * 255).astype(np.uint8)[200:420, 300:560].copy()
+    rows, cols = g.shape
+    ang = np.linspace(-np.pi, np.pi, B, endpoint=False)
+    dist = rng.uniform(5.0, 90.0, B)
+    x, y, th = cloud(rng, N, cols / 2, rows / 2, sxy=3.0, sth=0.3, th0=0.2)
+    seed = 99
+    for mode in (sa.capi.MODE_LOCALIZATION, sa.capi.MODE_SLAM):
+        slam = mode == sa.capi.MODE_SLAM
+        f = sa.Filter(N, rows, cols, mode=mode, seed=seed)
+        if not slam:
+            f.set_map(g)
+        f.set_poses(x, y, th)
+        state, maps = (x, y, th), (np.full((N, rows, cols), 128, np.uint8) if slam else g)
+        for step in range(3):
+            f.predict(ODOM, ALPHAS)
+            f.update(ang, dist, 5.0, 90.0, OFFSET)
+            ox, oy, oth = orc.predict(*state, ODOM, ALPHAS, orc.philox_normals(seed, step, 0, N), math=orc.DET)
+            ow, _ = orc.update_weights(ox, oy, oth, maps, ang, dist, 5.0, 90.0, OFFSET, slam_mode=slam, math=orc.DET)
+            idx, _, _ = orc.resample(ow, orc.philox_uniforms(seed, step, 0, N), orc.ORDER_BLOCKED)
+            src = idx[orc.sort_order(ow[idx], 0)]
+            state = (ox[src], oy[src], oth[src])
+            if slam:
+                maps = maps[src].copy()
+            assert np.array_equal(f.last_indices(), idx)
+            for q in range(3):
+                assert_bits(f.poses()[q], state[q], f"mode {mode}, pose column {q}, step {step}")
+            assert_bits(f.weights(), ow[src], f"mode {mode}, weights, step {step}")
+            if slam:
+                for p in range(N):
+                    assert np.array_equal(f.map_of(p), maps[p])
+        f.close()
+
+
 def test_weights_degenerate_underflow_and_tiny_ranges(sa):
     rng = np.random.default_rng(5)
     g = grid_of("floor_plan")
