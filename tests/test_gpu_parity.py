@@ -766,6 +766,55 @@ def test_sharded_filter_matches_single_handle(sa, shards, split):
     assert_bits(sf.b.f.poses()[0], ox[idx], "ShardedFilter world=1")
 
 
+def test_sharded_systematic_resampling(sa):
+    """Low-variance (systematic) resampling over shards: one draw for the whole filter, slot k of rank r
+    takes the cutoff (global k + u) * sum / N.  Four shards = one handle = the oracle."""
+    import torch
+
+    from slam_amd.dist import HipShard
+
+    rng = np.random.default_rng(12)
+    shards, N, B, seed = 4, 4200, 45, 0xABCD
+    n_loc = N // shards
+    free = orc.load_map("floor_plan")
+    g = (free * 255).astype(np.uint8)
+    rows, cols = g.shape
+    true = [520.0, 280.0, 0.4]
+    ang, dist = orc.make_scan(free, true, OFFSET, B)
+    x, y, th = cloud(rng, N, true[0], true[1], th0=true[2])
+    kw = dict(resampler=sa.capi.RESAMPLE_SYSTEMATIC)
+    single = sa.Filter(N, rows, cols, seed=seed, sort=sa.capi.SORT_NONE, **kw)
+    single.set_map(g)
+    single.set_poses(x, y, th)
+    backs = [HipShard(n_loc, rows, cols, r, shards, 0, seed, **kw) for r in range(shards)]
+    for r, b in enumerate(backs):
+        b.set_map(g)
+        b.f.set_poses(x[r * n_loc:(r + 1) * n_loc], y[r * n_loc:(r + 1) * n_loc], th[r * n_loc:(r + 1) * n_loc])
+    state = (x, y, th)
+    for step in range(3):
+        single.predict(ODOM, ALPHAS)
+        single.update(ang, dist, 5.0, 500.0, OFFSET)
+        for b in backs:
+            b.predict(ODOM, ALPHAS)
+            b.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+        gathered = torch.cat([b.packed_state() for b in backs])
+        torch.cuda.synchronize()
+        for b in backs:
+            b.shard_resample(gathered, shards)
+        ox, oy, oth = orc.predict(*state, ODOM, ALPHAS, orc.philox_normals(seed, step, 0, N), math=orc.DET)
+        ow, _ = orc.update_weights(ox, oy, oth, g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET)
+        idx, _, _ = orc.resample(ow, orc.philox_uniforms(seed, step, 0, N), orc.ORDER_BLOCKED, resampler=1)
+        state = (ox[idx], oy[idx], oth[idx])
+        assert np.all(np.diff(idx) >= 0)            # systematic: sources in order
+        assert np.array_equal(single.last_indices(), idx)
+        assert np.array_equal(np.concatenate([b.f.last_indices() for b in backs]), idx)
+        for q in range(3):
+            assert_bits(np.concatenate([b.f.poses()[q] for b in backs]), state[q], f"pose column {q}, step {step}")
+    single.close()
+    for b in backs:
+        b.f.close()
+
+
 def test_eight_shards_of_the_bench_size(sa):
     """The 8-GPU bench configuration (8 shards x 100 000 particles, floor plan), its shards emulated on
     one device: same selection, poses and weights as ONE handle of 800 000 particles."""
