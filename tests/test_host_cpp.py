@@ -73,3 +73,26 @@ def test_cpp_shim_matches_python_path(tmp_path, storage):
     pdf = [float(t) for t in next(ln for ln in out if ln.startswith("PDF")).split()[1:]]
     assert abs(pdf[0] - 0.18762017345846896) < 1e-15 and pdf[1] == 0.0 and pdf[2] == orc.pdf_triangular(1.5, [0.5])[0]
     assert next(ln for ln in out if ln.startswith("TRI")).split()[1] == "1"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("storage", ["dense", "tiled"])
+def test_cpp_shim_under_host_sanitizers(tmp_path, storage):
+    """The same call sequence against a build of the library whose host code is instrumented with
+    AddressSanitizer and UndefinedBehaviorSanitizer (`make -C tests/host_cpp san`, done by build()):
+    no report, and the same particles as the plain build."""
+    san = os.path.join(HERE, "host_cpp", "san", "mcl_san")
+    if not os.path.exists(san):
+        pytest.skip("sanitized build absent (make -C tests/host_cpp san)")
+    free = orc.load_map("floor_plan").astype(np.int32)
+    raw = tmp_path / "map.raw"
+    free.tofile(raw)
+    env = dict(os.environ, SLAM_SEED="4660", SLAM_MAPS=storage,
+               ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0", UBSAN_OPTIONS="print_stacktrace=1")
+    args = [str(raw), str(free.shape[0]), str(free.shape[1]), "4"]
+    got = subprocess.run([san] + args, env=env, capture_output=True, text=True, timeout=300)
+    assert got.returncode == 0, got.stderr[-2000:]
+    assert "ERROR" not in got.stderr and "runtime error" not in got.stderr, got.stderr[-2000:]
+    plain = subprocess.run([EXE] + args, env=env, capture_output=True, text=True, timeout=300, check=True)
+    pick = lambda out: [ln for ln in out.splitlines() if ln.startswith(("P ", "AVG", "MAP"))]
+    assert len(pick(got.stdout)) == 27 and pick(got.stdout) == pick(plain.stdout)
