@@ -96,3 +96,19 @@ def test_cpp_shim_under_host_sanitizers(tmp_path, storage):
     plain = subprocess.run([EXE] + args, env=env, capture_output=True, text=True, timeout=300, check=True)
     pick = lambda out: [ln for ln in out.splitlines() if ln.startswith(("P ", "AVG", "MAP"))]
     assert len(pick(got.stdout)) == 27 and pick(got.stdout) == pick(plain.stdout)
+
+
+@pytest.mark.gpu
+def test_abi_tour_under_host_sanitizers():
+    """tests/host_cpp/abi_tour.hip: every entry point of include/slam_hip.h called from C++ (both modes,
+    every kernel shape and option, two shards emulated on one device in all three exchange forms, the
+    documented error returns), against the ASan + UBSan host build of the library.  It checks sharded
+    against unsharded results itself; here: exit 0, its last line, no sanitizer report."""
+    exe = os.path.join(HERE, "host_cpp", "san", "abi_tour")
+    if not os.path.exists(exe):
+        pytest.skip("sanitized build absent (make -C tests/host_cpp san)")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0", UBSAN_OPTIONS="print_stacktrace=1")
+    got = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert got.returncode == 0, (got.stdout + got.stderr)[-2000:]
+    assert got.stdout.strip().endswith("abi_tour ok")
+    assert "ERROR" not in got.stderr and "runtime error" not in got.stderr, got.stderr[-2000:]
