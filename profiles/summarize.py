@@ -17,6 +17,32 @@ def kernel_stats(db):
     return "\n".join(out)
 
 
+def timed_region(db, steps=20):
+    """What bench.py's HIP events bracket: per kernel the average over the LAST `steps` launches (the
+    timed steps; rocprofv3's own averages include the warm-up steps, whose wide cloud makes them slower),
+    and the weighting pass as one span, from the start of k_order_keys to the end of k_sum_lw."""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    by = {}
+    for n, a, b in rows:
+        by.setdefault(n, []).append((a, b))
+    out = ["%-90s %8s %12s" % (f"kernel (last {steps} steps)", "launches", "avg_ns")]
+    per_step = {n: len(v) // max(len(by.get(next((k for k in by if "k_sum_lw" in k), n), [])), 1) for n, v in by.items()}
+    for n, v in sorted(by.items(), key=lambda kv: -sum(b - a for a, b in kv[1])):
+        k = max(per_step.get(n, 1), 1) * steps
+        if len(v) < k:
+            continue
+        tail = v[-k:]
+        out.append("%-90s %8d %12.0f" % (n[:90], len(tail), sum(b - a for a, b in tail) / len(tail)))
+    keys = [v for n, v in by.items() if "k_order_keys" in n]
+    sums = [v for n, v in by.items() if "k_sum_lw" in n]
+    if keys and sums and len(keys[0]) == len(sums[0]) >= steps:
+        spans = [e[1] - s[0] for s, e in zip(keys[0][-steps:], sums[0][-steps:])]
+        out.append("weighting pass, start of k_order_keys to end of k_sum_lw (= roofline.kernel_avg_ms of bench.py): "
+                   "avg %.0f ns over %d steps, min %d, max %d" % (sum(spans) / len(spans), len(spans), min(spans), max(spans)))
+    return "\n".join(out)
+
+
 def pmc_stats(db):
     cur = sqlite3.connect(db).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
@@ -73,6 +99,9 @@ def main(tag):
         lines.append(f"\n## {name}")
         try:
             lines.append(kernel_stats(d) if name == "trace" else pmc_stats(d))
+            if name == "trace":
+                lines.append("\n## timed region of the trace run (bench.py defaults: 5 warm-up + 20 timed steps)")
+                lines.append(timed_region(d))
         except Exception as e:  # noqa: BLE001
             lines.append(f"(could not read: {e})")
     text = "\n".join(lines) + "\n"
