@@ -95,7 +95,11 @@ __global__ void __launch_bounds__(256) k_place(const K* rk, const int* rv, int n
 
 // Wave-cooperative placement: lane u finds the window of run u that brackets the wavefront's 64 keys,
 // the windows are copied to LDS with coalesced loads and searched there.
-// STAGE 1: windows only, 2: + copy to LDS, 3: everything
+// STAGE 1: windows only, 2: + copy to LDS, 3: everything, 4: windows + loads only, 5: as 3 without fences.
+// Measured (100k keys with many duplicates, as weights after a resample have): windows 6 us, loads +3.5 us,
+// and the rest of the 49 us is the fallback for windows longer than WIN (runs of equal keys make them
+// long; they are searched per lane in memory, one run after the other).  Chunked LDS searches of long
+// windows are the next thing to try.
 enum { WIN = 192 };
 template <int STAGE>
 __global__ void __launch_bounds__(256) k_place_lds(const K* rk_all, const int* rv, int n, int n_runs, int* out)
@@ -159,15 +163,29 @@ __global__ void __launch_bounds__(256) k_place_lds(const K* rk_all, const int* r
 #pragma unroll
             for (int c = 0; c < WIN / 64; ++c)
             {
+                // clamped index, no select: lanes past the window re-read its last element
+                const int last = (w[u] <= WIN && w[u] > 0) ? w[u] - 1 : 0;
                 const int e = c * 64 + lane;
-                tmp[u][c] = rk[u][e < w[u] && w[u] <= WIN ? e : 0];
+                tmp[u][c] = rk[u][e < last ? e : last];
             }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // all window loads have landed before the first LDS store is issued
+        if (STAGE == 4)
+        {  // loads only
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < WIN / 64; ++c) rank += (int)(tmp[u][c] & 1);
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
             for (int c = 0; c < WIN / 64; ++c) win[u][c * 64 + lane] = tmp[u][c];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (STAGE != 5)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (STAGE >= 3)
         {
@@ -207,8 +225,11 @@ __global__ void __launch_bounds__(256) k_place_lds(const K* rk_all, const int* r
             }
             rank += wlo[u] + cnt[u];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (STAGE != 5)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
     }
     if (STAGE == 3)
     {
@@ -280,6 +301,8 @@ int main(int argc, char** argv)
     printf("k_place load + coalesced store only      %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_place<3>, pg, dim3(256), 0, 0, d_rk, d_rv, n, runs, d_out); }));
     printf("k_place_lds windows only                 %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_place_lds<1>, pg, dim3(256), 0, 0, d_rk, d_rv, n, runs, d_out); }));
     printf("k_place_lds windows + copy to LDS        %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_place_lds<2>, pg, dim3(256), 0, 0, d_rk, d_rv, n, runs, d_out); }));
+    printf("k_place_lds windows + loads only         %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_place_lds<4>, pg, dim3(256), 0, 0, d_rk, d_rv, n, runs, d_out); }));
+    printf("k_place_lds windows + LDS, no fences     %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_place_lds<5>, pg, dim3(256), 0, 0, d_rk, d_rv, n, runs, d_out); }));
     printf("k_place_lds full                         %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_place_lds<3>, pg, dim3(256), 0, 0, d_rk, d_rv, n, runs, d_out); }));
     CHECK(hipMemcpy(got.data(), d_out, sizeof(int) * n, hipMemcpyDeviceToHost));
     printf("permutation %s\n", got == ref ? "equals std::stable_sort" : "DIFFERS");
