@@ -239,6 +239,98 @@ __global__ void __launch_bounds__(256) k_place_lds(const K* rk_all, const int* r
         out[g] = rank;
 }
 
+// Chunked form: windows of any length go through LDS in chunks of WIN elements, eight runs per pass,
+// no per-lane searches in memory at all.
+__global__ void __launch_bounds__(256) k_place_chunks(const K* rk_all, const int* rv, int n, int n_runs, int* out)
+{
+    __shared__ K lds_win[4][8][WIN];
+    K(*win)[WIN] = lds_win[threadIdx.x >> 6];
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int r = g / TILE, q = g - r * TILE;
+    if (r >= n_runs) return;
+    const int left = n - r * TILE;
+    const int my_len = left < TILE ? left : TILE;
+    const int q0 = q - lane;
+    if (q0 >= my_len) return;
+    const int n_valid = my_len - q0 < 64 ? my_len - q0 : 64;
+    const bool valid = lane < n_valid;
+    const K key = rk_all[valid ? g : g - lane + n_valid - 1];
+    const K kmin = __shfl(key, 0, 64), kmax = __shfl(key, n_valid - 1, 64);
+    int lo = 0, hi = 0;
+    if (lane < n_runs && lane != r)
+    {
+        const int l = n - lane * TILE;
+        const int len = l < TILE ? l : TILE;
+        const K* rk = rk_all + (size_t)lane * TILE;
+        const bool ties = lane < r;
+        for (int s = TILE; s >= 1; s >>= 1)
+        {
+            const int ta = lo + s, tb = hi + s;
+            const K ka = rk[(ta <= len ? ta : 1) - 1], kb = rk[(tb <= len ? tb : 1) - 1];
+            if (ta <= len && (ties ? ka <= kmin : ka < kmin)) lo = ta;
+            if (tb <= len && (ties ? kb <= kmax : kb < kmax)) hi = tb;
+        }
+    }
+    int rank = q;
+    for (int j0 = 0; j0 < n_runs - 1; j0 += 8)
+    {
+        int w[8];
+        bool ties[8];
+        const K* rk[8];
+        int maxw = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+        {
+            const int j = j0 + u, rp = j < r ? j : j + 1;
+            const bool ok = j < n_runs - 1;
+            const int wlo = __shfl(lo, ok ? rp : r, 64);
+            w[u] = __shfl(hi, ok ? rp : r, 64) - wlo;
+            ties[u] = rp < r;
+            rk[u] = rk_all + (size_t)(ok ? rp : r) * TILE + wlo;
+            rank += wlo;
+            maxw = w[u] > maxw ? w[u] : maxw;
+        }
+        for (int base = 0; base < maxw; base += WIN)
+        {
+            K tmp[8][WIN / 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < WIN / 64; ++c)
+                {
+                    const int e = base + c * 64 + lane;
+                    const int last = w[u] > 0 ? w[u] - 1 : 0;
+                    tmp[u][c] = rk[u][e < last ? e : last];
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < WIN / 64; ++c) win[u][c * 64 + lane] = tmp[u][c];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 128; s >= 1; s >>= 1)  // WIN = 192 < 256
+            {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                {
+                    const int len = w[u] - base < WIN ? w[u] - base : WIN;  // elements of this chunk (<= 0: none)
+                    const int t = cnt[u] + s;
+                    const bool in = t <= len;
+                    const K kk = win[u][in ? t - 1 : 0];
+                    if (in && (ties[u] ? kk <= key : kk < key)) cnt[u] = t;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += cnt[u];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+    if (valid) out[rank] = rv[g];
+}
+
 template <class F>
 float time_us(F f, int reps = 50)
 {
@@ -304,6 +396,10 @@ int main(int argc, char** argv)
     printf("k_place_lds windows + loads only         %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_place_lds<4>, pg, dim3(256), 0, 0, d_rk, d_rv, n, runs, d_out); }));
     printf("k_place_lds windows + LDS, no fences     %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_place_lds<5>, pg, dim3(256), 0, 0, d_rk, d_rv, n, runs, d_out); }));
     printf("k_place_lds full                         %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_place_lds<3>, pg, dim3(256), 0, 0, d_rk, d_rv, n, runs, d_out); }));
+    CHECK(hipMemcpy(got.data(), d_out, sizeof(int) * n, hipMemcpyDeviceToHost));
+    printf("permutation %s\n", got == ref ? "equals std::stable_sort" : "DIFFERS");
+    CHECK(hipMemset(d_out, 0xff, sizeof(int) * n));
+    printf("k_place_chunks                           %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_place_chunks, pg, dim3(256), 0, 0, d_rk, d_rv, n, runs, d_out); }));
     CHECK(hipMemcpy(got.data(), d_out, sizeof(int) * n, hipMemcpyDeviceToHost));
     printf("permutation %s\n", got == ref ? "equals std::stable_sort" : "DIFFERS");
     return 0;
