@@ -378,6 +378,27 @@ int main(int argc, char** argv)
     printf("n = %d, %d runs\n", n, runs);
     printf("rocprim radix_sort_pairs (64-bit keys)   %8.2f us\n",
            time_us([&] { rocprim::radix_sort_pairs(tmp, bytes, d_in, d_k2, d_id, d_out2, (size_t)n, 0, 64, 0); }));
+    {
+        using namespace rocprim;
+        using c1 = radix_sort_config<default_config, merge_sort_config<512, 512, 8>, default_config>;
+        using c2 = radix_sort_config<default_config, merge_sort_config<512, 1024, 8>, default_config>;
+        using c3 = radix_sort_config<default_config, merge_sort_config<512, 256, 16>, default_config>;
+        using c4 = radix_sort_config<default_config, merge_sort_config<512, 512, 8, 128, 256, 8, 0>, default_config>;
+        using c5 = radix_sort_config<default_config, merge_sort_config<256, 256, 4, 128, 128, 4, 0>, default_config>;
+        size_t b1 = 0;
+        void* t1 = nullptr;
+#define TRY_CFG(cfg, label)                                                                                         \
+        b1 = 0;                                                                                                     \
+        CHECK((radix_sort_pairs<cfg>(nullptr, b1, d_in, d_k2, d_id, d_out2, (size_t)n, 0, 64, 0)));                \
+        CHECK(hipMalloc(&t1, b1 ? b1 : 16));                                                                        \
+        printf(label "  %8.2f us\n", time_us([&] { radix_sort_pairs<cfg>(t1, b1, d_in, d_k2, d_id, d_out2, (size_t)n, 0, 64, 0); })); \
+        CHECK(hipFree(t1));
+        TRY_CFG(c1, "rocprim merge sort, block sort 512x8, oddeven  ")
+        TRY_CFG(c2, "rocprim merge sort, block sort 1024x8, oddeven ")
+        TRY_CFG(c3, "rocprim merge sort, block sort 256x16, oddeven ")
+        TRY_CFG(c4, "rocprim merge sort, block sort 512x8, mergepath")
+        TRY_CFG(c5, "rocprim merge sort, block sort 256x4, mergepath")
+    }
     printf("k_runs<256>                              %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_runs<256>, dim3(runs), dim3(256), 0, 0, d_in, n, d_rk, d_rv); }));
     printf("k_runs<1024>                             %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_runs<1024>, dim3(runs), dim3(1024), 0, 0, d_in, n, d_rk, d_rv); }));
     const dim3 pg((runs * TILE + 255) / 256);
