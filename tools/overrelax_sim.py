@@ -4,11 +4,11 @@ import ctypes, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import _oracle as orc
+import bench
 d = os.path.join(ROOT, "tests", "host_harness")
 subprocess.run(["make", "-C", d, "-s"], check=True)
 hh = ctypes.CDLL(os.path.join(d, "libray_harness.so"))
-g = (orc.load_map("floor_plan") * 255).astype(np.uint8)
+g = (bench.load_free_grid("floor_plan") * 255).astype(np.uint8)
 rows, cols = g.shape
 E = np.empty_like(g)
 hh.hh_build_clearance(g.ctypes.data_as(ctypes.c_void_p), rows, cols, E.ctypes.data_as(ctypes.c_void_p))

@@ -7,10 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import slam_amd as sa
 from slam_amd import capi, synth
-import _oracle as orc
+import bench
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", 1)))
-maps = {n: (orc.load_map(n) * 255).astype(np.uint8) for n in ("floor_plan", "map", "maze")}
+maps = {n: (bench.load_free_grid(n) * 255).astype(np.uint8) for n in ("floor_plan", "map", "maze")}
 maps["synth2048"] = synth.make_grid(2048)
 t0 = time.time(); cases = 0; rays = 0
 while time.time() - t0 < budget:
