@@ -256,6 +256,25 @@ int slam_raycast_u8(int32_t device, const uint8_t* map, int32_t rows, int32_t co
 int slam_raycast_batch(int32_t device, int32_t kind, const uint8_t* map, int32_t rows, int32_t cols, const double* poses3,
                        int64_t n, double max_distance_squared, double step_size, double* hits_xy);
 
+/* The one entry point that allocates nothing.  It has NO counterpart in the reference; it exists for
+ * callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid allocation.  It is the selection half of slam_mcl_resample (slam/mcl.cpp:157-203: running
+ * sum of the weights in the canonical blocked order of SLAM_PREFIX_BLOCKED, then the reference's
+ * bisection per output slot) as a stateless call on device buffers: weights_dev[n] in (finite, >= 0:
+ * not checked, they live on the device), idx_dev[n] out; identical indices to a handle of n particles
+ * given the same weights and uniforms.  uniforms_dev: n canonical uniforms in [0,1) (systematic: one),
+ * or NULL for the Philox stream (seed, step, slot) a handle would draw.  The running-sum levels live in
+ * a static device array of the library (about 4.3 MB per GPU, held until the process ends), so
+ * n <= SLAM_SELECT_STATIC_MAX; larger n is rejected with SLAM_ERR_ARG.  The call only enqueues on
+ * `stream` (no synchronisation, no hipMalloc/hipFree); every call on one GPU shares that GPU's array,
+ * so calls that overlap on one GPU (different streams) race: order them.  slam_static_init(device)
+ * does the one-time per-device set-up (looks up the array's address) ahead of time, e.g. before a
+ * graph capture; otherwise the first call on a device does it. */
+#define SLAM_SELECT_STATIC_MAX 262144
+int slam_static_init(int32_t device);
+int slam_resample_select_static(int32_t device, void* stream, const double* weights_dev, int64_t n, int32_t resampler,
+                                const double* uniforms_dev, uint64_t seed, uint64_t step, int32_t* idx_dev);
+
 #ifdef __cplusplus
 }
 #endif

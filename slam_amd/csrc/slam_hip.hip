@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <rocprim/rocprim.hpp>
 #include <string>
@@ -524,6 +525,34 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     return SLAM_OK;
 }
 
+// Canonical blocked running sum of `in` (nullptr: the weight column of `view`) into u.P[0].
+// u.n[l] = entries of level l (n[0] = all weights, n[l+1] = ceil(n[l] / 64), the last level holds <= 64);
+// the top level's P is its s (same buffer).  Launches only; allocates nothing.
+void launch_blocked_prefix(hipStream_t stream, const double* in, const slamk::StateView& view, const slamk::UpperLevels& u)
+{
+    const int L = u.L;
+    if (L >= 3 && L <= 8 && u.n[1] <= 65536)
+    {
+        // the small upper levels in one launch (3 launches for 100k particles instead of 5)
+        hipLaunchKernelGGL(slamk::k_scan_chunks, dim3((unsigned)cdiv(cdiv(u.n[0], 64), 4)), dim3(256), 0, stream, in, view, u.n[0],
+                           u.s[0], u.tot[0]);
+        hipLaunchKernelGGL(slamk::k_scan_upper, dim3(1), dim3(1024), 0, stream, u);
+        hipLaunchKernelGGL(slamk::k_downsweep, dim3((unsigned)cdiv(u.n[0], 256)), dim3(256), 0, stream, u.s[0], u.P[1], u.n[0],
+                           u.P[0]);
+        return;
+    }
+    for (int l = 0; l < L; ++l)
+    {
+        hipLaunchKernelGGL(slamk::k_scan_chunks, dim3((unsigned)cdiv(cdiv(u.n[l], 64), 4)), dim3(256), 0, stream, in, view, u.n[l],
+                           u.s[l], u.tot[l]);
+        in = u.tot[l];
+    }
+    // top level: P = s (same buffer); lower levels add the earlier chunks' sum
+    for (int l = L - 2; l >= 0; --l)
+        hipLaunchKernelGGL(slamk::k_downsweep, dim3((unsigned)cdiv(u.n[l], 256)), dim3(256), 0, stream, u.s[l], u.P[l + 1], u.n[l],
+                           u.P[l]);
+}
+
 // running sums of the weights of all shards (n_glob entries) into lvl_P[0], in the configured order
 int do_prefix(slam_mcl* h, const slamk::StateView& view)
 {
@@ -555,42 +584,16 @@ int do_prefix(slam_mcl* h, const slamk::StateView& view)
         HIPCHK(hipGetLastError());
         return SLAM_OK;
     }
-    const int L = (int)h->lvl_n.size();
-    const double* in = lin;  // nullptr: level 0 reads the weight column of the view
-    if (L >= 3 && L <= 8 && h->lvl_n[1] <= 65536)
+    slamk::UpperLevels u;
+    u.L = (int)h->lvl_n.size();
+    for (int l = 0; l < u.L; ++l)
     {
-        // the small upper levels in one launch (3 launches for 100k particles instead of 5)
-        hipLaunchKernelGGL(slamk::k_scan_chunks, dim3((unsigned)cdiv(cdiv(h->lvl_n[0], 64), 4)), dim3(256), 0, h->stream, in, view,
-                           h->lvl_n[0], h->lvl_s[0], h->lvl_tot[0]);
-        slamk::UpperLevels u;
-        u.L = L;
-        for (int l = 0; l < L; ++l)
-        {
-            u.n[l] = h->lvl_n[l];
-            u.s[l] = h->lvl_s[l];
-            u.tot[l] = h->lvl_tot[l];
-            u.P[l] = h->lvl_P[l];
-        }
-        hipLaunchKernelGGL(slamk::k_scan_upper, dim3(1), dim3(1024), 0, h->stream, u);
-        hipLaunchKernelGGL(slamk::k_downsweep, dim3((unsigned)cdiv(h->lvl_n[0], 256)), dim3(256), 0, h->stream, h->lvl_s[0],
-                           h->lvl_P[1], h->lvl_n[0], h->lvl_P[0]);
-        HIPCHK(hipGetLastError());
-        return SLAM_OK;
+        u.n[l] = h->lvl_n[l];
+        u.s[l] = h->lvl_s[l];
+        u.tot[l] = h->lvl_tot[l];
+        u.P[l] = h->lvl_P[l];
     }
-    for (int l = 0; l < L; ++l)
-    {
-        const int64_t nl = h->lvl_n[l];
-        hipLaunchKernelGGL(slamk::k_scan_chunks, dim3((unsigned)cdiv(cdiv(nl, 64), 4)), dim3(256), 0, h->stream, in, view,
-                           nl, h->lvl_s[l], h->lvl_tot[l]);
-        in = h->lvl_tot[l];
-    }
-    // top level: P = s (same buffer, see create); lower levels add the earlier chunks' sum
-    for (int l = L - 2; l >= 0; --l)
-    {
-        const int64_t nl = h->lvl_n[l];
-        hipLaunchKernelGGL(slamk::k_downsweep, dim3((unsigned)cdiv(nl, 256)), dim3(256), 0, h->stream, h->lvl_s[l],
-                           h->lvl_P[l + 1], nl, h->lvl_P[l]);
-    }
+    launch_blocked_prefix(h->stream, lin, view, u);
     HIPCHK(hipGetLastError());
     return SLAM_OK;
 }
@@ -1626,4 +1629,117 @@ SLAM_API int slam_raycast_batch(int32_t device, int32_t kind, const uint8_t* map
     }
     return kind == 1 ? raycast_batch<1>(device, map, rows, cols, px, py, pth, max_distance_squared, step_size, hits_xy)
                      : raycast_batch<2>(device, map, rows, cols, px, py, pth, max_distance_squared, step_size, hits_xy);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The entry point that allocates nothing (include/slam_hip.h: slam_resample_select_static).
+// The running-sum hierarchy of the selection (levels s / P / tot of launch_blocked_prefix, what
+// slam_mcl_create allocates per handle) lives in ONE file-scope device array per GPU; it is held
+// until the process ends.  `scratch` itself is only a host-side stand-in: kernels get the address
+// hipGetSymbolAddress returned for the current device, never the array's name.
+namespace
+{
+constexpr int64_t kStaticMaxN = SLAM_SELECT_STATIC_MAX;
+constexpr size_t static_round(size_t doubles) { return (doubles * sizeof(double) + 255) / 256 * 256; }
+constexpr size_t static_level_bytes(int64_t n, bool top)
+{
+    // s[n], P[n] (the top level's P is its s), tot[ceil(n / 64)]
+    return static_round((size_t)n) * (top ? 1 : 2) + static_round((size_t)((n + 63) / 64));
+}
+constexpr size_t static_total_bytes(int64_t n) { return n <= 64 ? static_level_bytes(n, true) : static_level_bytes(n, false) + static_total_bytes((n + 63) / 64); }
+constexpr size_t kStaticBytes = static_total_bytes(kStaticMaxN);
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+namespace
+{
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices];  // per device: the address of that device's copy of `scratch`
+bool g_scratch_ok[kMaxDevices];
+
+// once per device, with that device current
+int static_scratch(int device, unsigned char** out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(SLAM_ERR_ARG, "device ordinal out of range");
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!g_scratch_ok[device])
+    {
+        void* p = nullptr;
+        HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(SLAM_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+        g_scratch_ok[device] = true;
+    }
+    *out = g_scratch_ptr[device];
+    return SLAM_OK;
+}
+}  // namespace
+
+SLAM_API int slam_static_init(int32_t device)
+{
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(SLAM_ERR_ARG, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    unsigned char* p = nullptr;
+    return static_scratch(device, &p);
+}
+
+SLAM_API int slam_resample_select_static(int32_t device, void* stream, const double* weights_dev, int64_t n, int32_t resampler,
+                                         const double* uniforms_dev, uint64_t seed, uint64_t step, int32_t* idx_dev)
+{
+    if (!weights_dev || !idx_dev) return fail(SLAM_ERR_ARG, "select_static: null pointer");
+    if (n < 1 || n > kStaticMaxN)
+        return fail(SLAM_ERR_ARG, "select_static: n must be in [1, " + std::to_string(kStaticMaxN) +
+                                      "] (SLAM_SELECT_STATIC_MAX: the size of the static scratch array); use slam_mcl_resample beyond");
+    if (resampler != SLAM_RESAMPLE_MULTINOMIAL && resampler != SLAM_RESAMPLE_SYSTEMATIC)
+        return fail(SLAM_ERR_ARG, "select_static: bad resampler");
+    int rc = slam_static_init(device);
+    if (rc) return rc;
+    unsigned char* base = nullptr;
+    if ((rc = static_scratch(device, &base))) return rc;
+    // carve the levels out of the array exactly as static_total_bytes counted them
+    slamk::UpperLevels u;
+    u.L = 0;
+    size_t at = 0;
+    for (int64_t nl = n;; nl = cdiv(nl, 64))
+    {
+        const int l = u.L++;
+        const bool top = nl <= 64;
+        u.n[l] = nl;
+        u.s[l] = reinterpret_cast<double*>(base + at);
+        at += static_round((size_t)nl);
+        u.P[l] = u.s[l];
+        if (!top)
+        {
+            u.P[l] = reinterpret_cast<double*>(base + at);
+            at += static_round((size_t)nl);
+        }
+        u.tot[l] = reinterpret_cast<double*>(base + at);
+        at += static_round((size_t)cdiv(nl, 64));
+        if (top) break;
+    }
+    if (at > kStaticBytes) return fail(SLAM_ERR_STATE, "select_static: scratch layout exceeds the static array (library bug)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    slamk::StateView none = {nullptr, 1, nullptr};
+    // (every scratch entry that is read has been written by this call: nothing needs clearing)
+    launch_blocked_prefix(st, weights_dev, none, u);
+    slamk::SelectArgs s;
+    s.P = u.P[0];
+    s.n_total = n;
+    s.slot_first = 0;
+    s.n_slots = n;
+    s.injected = uniforms_dev;
+    s.seed = seed;
+    s.step = step;
+    s.resampler = resampler;
+    s.idx = idx_dev;
+    s.view = none;
+    s.keys = nullptr;
+    s.slots = nullptr;
+    hipLaunchKernelGGL(slamk::k_select, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, s);
+    HIPCHK(hipGetLastError());
+    return SLAM_OK;
 }
