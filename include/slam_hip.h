@@ -44,7 +44,13 @@ enum
     SLAM_RAYCAST_FAST = 0,                /* clearance-skipping search; kernel shape chosen by N */
     SLAM_RAYCAST_WALK = 1,                /* literal cell-by-cell walk (counts cells) */
     SLAM_RAYCAST_FAST_BEAM_LANES = 2,     /* force: one wavefront per particle, lanes over beams */
-    SLAM_RAYCAST_FAST_PARTICLE_LANES = 3  /* force: lane = particle, work item = (64 particles, beam segment) */
+    SLAM_RAYCAST_FAST_PARTICLE_LANES = 3, /* force: lane = particle, work item = (64 particles, beam segment) */
+    SLAM_RAYCAST_TWO_PHASE = 4,           /* SLAM mode, force: geometry of 64 rays at once (lane = beam), then the rays
+                                             in order, 64 samples per pass (what SLAM_RAYCAST_FAST picks in SLAM mode
+                                             below 262144 particles; 2 forces the older wave-per-ray form) */
+    SLAM_RAYCAST_TWO_PHASE_LITERAL = 5    /* test hook: the two-phase kernel with every batch of beams on its literal
+                                             fallback loop (taken by itself only when rounding makes a cell index move by
+                                             two in one sample) */
 };
 
 /* Construction parameters.  Zero-initialise, set struct_size = sizeof(slam_mcl_params), fill in.

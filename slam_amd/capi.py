@@ -16,7 +16,7 @@ SORT_FULL, SORT_NONE = 0, 1
 WEIGHT_LINEAR, WEIGHT_LOG = 0, 1
 TILE_SIDE, TILE_BYTES = 64, 4096  # SLAM_TILE_SIDE, SLAM_TILE_BYTES of include/slam_hip.h
 MAPS_AUTO, MAPS_DENSE, MAPS_TILED = 0, 1, 2
-RAYCAST_FAST, RAYCAST_WALK, RAYCAST_FAST_BEAM_LANES, RAYCAST_FAST_PARTICLE_LANES = 0, 1, 2, 3
+RAYCAST_FAST, RAYCAST_WALK, RAYCAST_FAST_BEAM_LANES, RAYCAST_FAST_PARTICLE_LANES, RAYCAST_TWO_PHASE, RAYCAST_TWO_PHASE_LITERAL = 0, 1, 2, 3, 4, 5
 
 
 class SlamError(RuntimeError):

@@ -3,7 +3,7 @@
 // Kernel groups (SURVEY.md §2 "what the build writes instead"):
 //   K1  k_predict            slam/motion.cpp:9-32 + slam/util.cpp:45-51, one thread per particle
 //   K2a k_weights_L          localization mode: one wavefront per particle, lanes over beams
-//   K2b k_weights_S          SLAM mode: slam/raycast.cpp:143-223 with map updates, beams in order
+//   K2b k_weights_S2 (slam_s2.h, the default), k_weights_S_wave, k_weights_S   SLAM mode: slam/raycast.cpp:143-223 with map updates, beams in order
 //   K3  k_scan_chunks / k_downsweep / k_prefix_seq / k_select / k_gather   slam/mcl.cpp:157-203
 //   K4  sort keys + gather (rocPRIM radix sort drives the permutation)     slam/mcl.cpp:232-239
 #pragma once
@@ -993,9 +993,8 @@ __global__ void __launch_bounds__(256) k_set_sectors(SectorTable t, float* out) 
 
 // Before a weighting pass: every tile a particle may write (within `range` cells of its sensor) that
 // it does not own yet is copied to a fresh tile, instead of one at a time inside k_weights_S_wave.
-// k_tile_plan: one block per particle lists those tiles and takes ONE range of the free list for
-// them (a single atomic per particle: the allocation cursor is one address).  k_tile_copy: one
-// block per listed tile copies it and repoints the table.  Conservative in both directions is
+// k_tile_plan lists those tiles and takes one range of the free list per block of 64 particles
+// (the allocation cursor is one address).  k_tile_copy copies the listed tiles and repoints the tables.  Conservative in both directions is
 // fine: a tile copied needlessly costs 4 KiB, a tile missed is copied by the kernel.
 struct TilePlan
 {
@@ -1007,92 +1006,133 @@ struct TilePlan
 // all the sectors it spans is not copied (a wall at 100 cells stops the writes there although the
 // sensor's range is 500).  Approximate on purpose (float, margins): a miss only moves the copy
 // into the walk kernel.
-__global__ void __launch_bounds__(256) k_tile_plan(int64_t n, const double* x, const double* y, const double* th, double sd,
-                                                   double stheta, double srot, double range, const float* sector_r, int rows,
-                                                   int cols, int side, TileArgs ta, TilePlan pl)
+enum { TILE_PLAN_PW = 4 };  // particles per wavefront of k_tile_plan (16 wavefronts per block: 64 particles per atomic)
+
+struct TilePlanCtx
+{
+    double sc, sr, range, heading;
+    bool sane;
+    int ti_first, tj_first, side, trows, tcols;
+    const int32_t* tab_p;
+    const float* sector_r;
+    // does the particle need a private copy of the q-th tile of its square?  (*t = its table slot)
+    __device__ __forceinline__ bool need(int q, int* t) const
+    {
+        const int ti = ti_first + q / side, tj = tj_first + q % side;
+        *t = ti * tcols + tj;
+        if (!(q < side * side && sane && ti >= 0 && tj >= 0 && ti < trows && tj < tcols)) return false;
+        const double r0 = (double)(ti << TILE_SHIFT), c0 = (double)(tj << TILE_SHIFT);
+        const double dr = sr < r0 ? r0 - sr : (sr > r0 + 64.0 ? sr - (r0 + 64.0) : 0.0);
+        const double dc = sc < c0 ? c0 - sc : (sc > c0 + 64.0 ? sc - (c0 + 64.0) : 0.0);
+        const double dmin2 = dr * dr + dc * dc;
+        if (!(dmin2 <= range * range) || (tab_p[*t] & TILE_OWN)) return false;
+        const float dxw = (float)(c0 + 32.0 - sc), dyw = (float)(sr - (r0 + 32.0));  // to the tile's centre, y up
+        const float dcen = sqrtf(dxw * dxw + dyw * dyw);
+        if (dcen > 100.0f)
+        {
+            const float inv = 40.743665f;  // 256 / (2 pi)
+            const float alpha = atan2f(dyw, dxw) - (float)heading;
+            const float half = asinf(46.0f / dcen) * inv + 1.5f;  // half-diagonal of a tile, plus margin, in sectors
+            const int k0 = (int)floorf(alpha * inv - half), k1 = (int)floorf(alpha * inv + half);
+            float rmax = 0.0f;
+            for (int k = k0; k <= k1; ++k) rmax = fmaxf(rmax, sector_r[(k + 128) & 255]);
+            return dmin2 <= (double)rmax * (double)rmax;
+        }
+        return true;
+    }
+};
+
+// One wavefront per TILE_PLAN_PW particles, 16 wavefronts per block; the tiles are evaluated twice (count, then
+// list) so that a whole block takes ONE range of the free list: the allocation cursor is a single
+// address, and one atomic per particle on it cost more than everything else in this kernel.
+__global__ void __launch_bounds__(1024) k_tile_plan(int64_t n, const double* x, const double* y, const double* th, double sd,
+                                                    double stheta, double srot, double range, const float* sector_r, int rows,
+                                                    int cols, int side, TileArgs ta, TilePlan pl)
 {
     __shared__ int cnt_s, base_s;
-    const int64_t p = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) cnt_s = 0;
     __syncthreads();
-    double s, c;
-    dm_sincos(th[p] + stheta, &s, &c);
-    const double sc = x[p] + c * sd;                           // sensor column
-    const double sr = ((double)rows - (y[p] + s * sd)) - 1.0;  // sensor row
-    const bool sane = dm_fabs(sc) < 1.0e9 && dm_fabs(sr) < 1.0e9;
-    const int half = side >> 1;
-    const int trows = ta.tiles_per_map / ta.tcols;
-    const int32_t* tab_p = ta.tab + (size_t)p * ta.tiles_per_map;
-    int mine_t[4], mine_i[4], nmine = 0;  // side <= 31 keeps this within 4 per thread; larger squares loop further
-    for (int q = threadIdx.x; q < side * side; q += blockDim.x)
+    const int64_t p_first = ((int64_t)blockIdx.x * 16 + wave) * TILE_PLAN_PW;
+    int wave_total = 0;
+    int wave_off = 0;
+    for (int pass = 0; pass < 2; ++pass)
     {
-        const int ti = (slam_f2i(sr) >> TILE_SHIFT) - half + q / side;
-        const int tj = (slam_f2i(sc) >> TILE_SHIFT) - half + q % side;
-        bool need = sane && ti >= 0 && tj >= 0 && ti < trows && tj < ta.tcols;
-        if (need)
+        int running = 0;
+        for (int k = 0; k < TILE_PLAN_PW; ++k)
         {
-            const double r0 = (double)(ti << TILE_SHIFT), c0 = (double)(tj << TILE_SHIFT);
-            const double dr = sr < r0 ? r0 - sr : (sr > r0 + 64.0 ? sr - (r0 + 64.0) : 0.0);
-            const double dc = sc < c0 ? c0 - sc : (sc > c0 + 64.0 ? sc - (c0 + 64.0) : 0.0);
-            const double dmin2 = dr * dr + dc * dc;
-            need = dmin2 <= range * range && !(tab_p[ti * ta.tcols + tj] & TILE_OWN);
-            const float dxw = (float)(c0 + 32.0 - sc), dyw = (float)(sr - (r0 + 32.0));  // to the tile's centre, y up
-            const float dcen = sqrtf(dxw * dxw + dyw * dyw);
-            if (need && dcen > 100.0f)
+            const int64_t p = p_first + k;
+            if (p >= n) break;  // whole wavefront
+            double s, c;
+            dm_sincos(th[p] + stheta, &s, &c);
+            TilePlanCtx cx;
+            cx.sc = x[p] + c * sd;                           // sensor column
+            cx.sr = ((double)rows - (y[p] + s * sd)) - 1.0;  // sensor row
+            cx.sane = dm_fabs(cx.sc) < 1.0e9 && dm_fabs(cx.sr) < 1.0e9;
+            cx.range = range;
+            cx.heading = th[p] + srot;
+            cx.side = side;
+            cx.ti_first = (slam_f2i(cx.sr) >> TILE_SHIFT) - (side >> 1);
+            cx.tj_first = (slam_f2i(cx.sc) >> TILE_SHIFT) - (side >> 1);
+            cx.trows = ta.tiles_per_map / ta.tcols;
+            cx.tcols = ta.tcols;
+            cx.tab_p = ta.tab + (size_t)p * ta.tiles_per_map;
+            cx.sector_r = sector_r;
+            for (int q0 = 0; q0 < side * side; q0 += 64)
             {
-                const float inv = 40.743665f;  // 256 / (2 pi)
-                const float alpha = atan2f(dyw, dxw) - (float)(th[p] + srot);
-                const float half = asinf(46.0f / dcen) * inv + 1.5f;  // half-diagonal of a tile, plus margin, in sectors
-                const int k0 = (int)floorf(alpha * inv - half), k1 = (int)floorf(alpha * inv + half);
-                float rmax = 0.0f;
-                for (int k = k0; k <= k1; ++k) rmax = fmaxf(rmax, sector_r[(k + 128) & 255]);
-                need = dmin2 <= (double)rmax * (double)rmax;
+                int t;
+                const bool need = cx.need(q0 + lane, &t);
+                const uint64_t vote = __ballot(need);
+                if (pass == 1 && need)
+                {
+                    const int pos = base_s + wave_off + running +
+                                    (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0));
+                    if (pos < ta.ctrl[1])
+                    {
+                        pl.wl_p[pos] = (int32_t)p;
+                        pl.wl_t[pos] = t;
+                    }
+                    else
+                        ta.ctrl[2] = 1;  // pool exhausted
+                }
+                running += __builtin_popcountll(vote);
             }
         }
-        if (need && nmine < 4)
+        if (pass == 0)
         {
-            mine_t[nmine] = ti * ta.tcols + tj;
-            mine_i[nmine] = atomicAdd(&cnt_s, 1);
-            ++nmine;
+            wave_total = running;
+            if (lane == 0 && wave_total) wave_off = atomicAdd(&cnt_s, wave_total);
+            wave_off = __builtin_amdgcn_readfirstlane(wave_off);
+            __syncthreads();
+            if (threadIdx.x == 0) base_s = cnt_s ? atomicAdd(&ta.ctrl[0], cnt_s) : 0;
+            __syncthreads();
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) base_s = cnt_s ? atomicAdd(&ta.ctrl[0], cnt_s) : 0;
-    __syncthreads();
-    const int nfree = ta.ctrl[1];
-    for (int k = 0; k < nmine; ++k)
-    {
-        const int pos = base_s + mine_i[k];
-        if (pos < nfree)
-        {
-            pl.wl_p[pos] = (int32_t)p;
-            pl.wl_t[pos] = mine_t[k];
-        }
-        else
-            ta.ctrl[2] = 1;  // pool exhausted
     }
 }
 
-// first = allocation cursor before k_tile_plan (ctrl[3]); block b takes free-list position first + b
+// first = allocation cursor before k_tile_plan (ctrl[3]); block b takes free-list positions first + b,
+// first + b + gridDim.x, ... (the grid is bounded: how many tiles the plan listed is known on the device only,
+// and a grid sized for the worst case spends milliseconds launching empty workgroups)
 __global__ void __launch_bounds__(256) k_tile_copy(TileArgs ta, TilePlan pl)
 {
-    const int64_t pos = (int64_t)ta.ctrl[3] + blockIdx.x;
     const int end = ta.ctrl[0] < ta.ctrl[1] ? ta.ctrl[0] : ta.ctrl[1];
-    if (pos >= end) return;
-    const int p = pl.wl_p[pos];
-    if (p < 0) return;
-    const int t = pl.wl_t[pos];
-    int32_t* tab_p = ta.tab + (size_t)p * ta.tiles_per_map;
-    const int old = tab_p[t] & ~TILE_OWN;
-    const int nid = ta.freelist[pos];
-    const uint4* from = reinterpret_cast<const uint4*>(ta.pool + (size_t)old * TILE_BYTES);
-    uint4* to = reinterpret_cast<uint4*>(ta.pool + (size_t)nid * TILE_BYTES);
-    to[threadIdx.x] = from[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0)
+    for (int64_t pos = (int64_t)ta.ctrl[3] + blockIdx.x; pos < end; pos += gridDim.x)
     {
-        tab_p[t] = nid | TILE_OWN;
-        pl.wl_p[pos] = -1;
+        const int p = pl.wl_p[pos];
+        if (p < 0) continue;
+        const int t = pl.wl_t[pos];
+        int32_t* tab_p = ta.tab + (size_t)p * ta.tiles_per_map;
+        const int old = tab_p[t] & ~TILE_OWN;
+        const int nid = ta.freelist[pos];
+        const uint4* from = reinterpret_cast<const uint4*>(ta.pool + (size_t)old * TILE_BYTES);
+        uint4* to = reinterpret_cast<uint4*>(ta.pool + (size_t)nid * TILE_BYTES);
+        to[threadIdx.x] = from[threadIdx.x];
+        __syncthreads();  // (the table entry is read above by every thread before thread 0 repoints it)
+        if (threadIdx.x == 0)
+        {
+            tab_p[t] = nid | TILE_OWN;
+            pl.wl_p[pos] = -1;
+        }
     }
 }
 
@@ -1395,3 +1435,5 @@ __global__ void __launch_bounds__(256) k_raycast_ro(const uint8_t* map, int rows
 }
 
 }  // namespace slamk
+
+#include "slam_s2.h"

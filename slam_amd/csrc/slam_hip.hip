@@ -253,6 +253,8 @@ struct Tuning
     int order_bits;  // SLAM_PL_ORDER_BITS: bits of the order key that are sorted
     int seg_beams;   // SLAM_PL_SEG: beams per work item (0 = chosen from the launch size)
     int waves;       // SLAM_PL_WAVES: wavefronts per SIMD the ray kernel is compiled for (4, 5, 6 or 8)
+    int s_kernel;    // SLAM_S_KERNEL: 0 = default (two-phase SLAM-mode kernel), 1 = legacy wave-per-ray kernel,
+                     // 2 = two-phase kernel with every batch on its literal fallback (tests)
 };
 const Tuning& tuning()
 {
@@ -261,7 +263,7 @@ const Tuning& tuning()
         return v ? atoi(v) : dflt;
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
-                             env_int("SLAM_PL_WAVES", 5)};
+                             env_int("SLAM_PL_WAVES", 5), env_int("SLAM_S_KERNEL", 0)};
     return t;
 }
 
@@ -397,6 +399,17 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         const bool wave = h->prm.raycaster == SLAM_RAYCAST_FAST_BEAM_LANES ||
                           (h->prm.raycaster != SLAM_RAYCAST_FAST_PARTICLE_LANES && h->n < 262144);
         slamk::TileArgs ta = {h->tile_pool, h->tile_tab, h->tile_T, h->tile_tc, h->tile_free, h->tile_ctrl, 0};
+        // two-phase kernel (k_weights_S2): the default wherever the wave form would run, as long as the
+        // geometry bits of 64 rays (and the table window) fit the LDS of one wavefront
+        const int npass = (a.max_iter + 63) / 64;
+        const int win_w = 2 * npass + 2;
+        const size_t s2_lds = 512 + (size_t)npass * 1024 + (h->tiled ? (size_t)win_w * win_w * 4 : 0);
+        const bool two_phase = s2_lds <= 60 * 1024 && tuning().s_kernel != 1 &&
+                               (h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE || h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE_LITERAL ||
+                                (h->prm.raycaster == SLAM_RAYCAST_FAST && wave));
+        const int s2_literal = (tuning().s_kernel == 2 || h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE_LITERAL) ? 1 : 0;
+        if ((h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE || h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE_LITERAL) && !two_phase)
+            return fail(SLAM_ERR_ARG, "SLAM_RAYCAST_TWO_PHASE: max_dist too large for the LDS of one wavefront");
         if (h->tiled)
         {
             // make every tile within sensor range exclusive up front (parallel), then walk
@@ -405,7 +418,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             const int span = 2 * std::max(h->tile_T / h->tile_tc, h->tile_tc) + 1;
             const int side = std::min(std::min(2 * (int)std::ceil(std::fmin(range, 1.0e6) / 64.0) + 3, span), 31);
             const int64_t per = std::min<int64_t>((int64_t)side * side, h->tile_T);
-            const int64_t blocks = std::min<int64_t>(h->n * per, h->tile_cap);
+            const int64_t blocks = std::min<int64_t>(std::min<int64_t>(h->n * per, h->tile_cap), 16384);
             slamk::TilePlan pl = {h->tile_wl_p, h->tile_wl_t};
             {
                 // per sector of the scan frame (sector k covers angles [-pi + k 2pi/256, ...)): the farthest write
@@ -427,7 +440,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 hipLaunchKernelGGL(slamk::k_set_sectors, dim3(1), dim3(256), 0, h->stream, dil, h->tile_sector);
             }
             hipLaunchKernelGGL(slamk::k_tile_mark, dim3(1), dim3(1), 0, h->stream, h->tile_ctrl);
-            hipLaunchKernelGGL(slamk::k_tile_plan, dim3((unsigned)h->n), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th, a.sd,
+            hipLaunchKernelGGL(slamk::k_tile_plan, dim3((unsigned)cdiv(h->n, 16 * slamk::TILE_PLAN_PW)), dim3(1024), 0, h->stream, h->n, h->x, h->y, h->th, a.sd,
                                a.stheta, a.srot, range, h->tile_sector, h->rows, h->cols, side, ta, pl);
             hipLaunchKernelGGL(slamk::k_tile_copy, dim3((unsigned)blocks), dim3(256), 0, h->stream, ta, pl);
             size_t lds = 0;
@@ -436,8 +449,15 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 ta.lds_entries = h->tile_T;
                 lds = (size_t)h->tile_T * 16;
             }
-            hipLaunchKernelGGL(slamk::k_weights_S_wave<true>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), lds, h->stream, a, ta);
+            if (two_phase)
+                hipLaunchKernelGGL(slamk::k_weights_S2<true>, dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
+                                   s2_literal);
+            else
+                hipLaunchKernelGGL(slamk::k_weights_S_wave<true>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), lds, h->stream, a, ta);
         }
+        else if (two_phase)
+            hipLaunchKernelGGL(slamk::k_weights_S2<false>, dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
+                               s2_literal);
         else if (wave)
             hipLaunchKernelGGL(slamk::k_weights_S_wave<false>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a, ta);
         else

@@ -1,0 +1,588 @@
+// slam_s2.h — K2b, two-phase form: the SLAM-mode weighting kernel (included by kernels.h).
+//
+// Reproduces slam/raycast.cpp:143-223 (raycast_mapping with its occupancy update) for every beam of
+// a particle IN ORDER (slam/mcl.cpp:69-74: later beams see earlier beams' writes), then
+// slam/raycast.cpp:225-242 and the beam-order sum of slam/mcl.cpp:67-75.  One wavefront = one particle.
+//
+// Phase A, lane = beam (64 beams at once), map-independent: every lane walks its own ray with the
+// literal x += dx, y += dy of slam/raycast.cpp:165-166 and records, per sample, whether the row and
+// whether the column of the cell changed (2 bits per sample, 64 samples = one uint4 per beam in
+// LDS).  Cell indices move monotonically along a ray and by at most one per sample, so the cell of
+// sample k is the start cell plus the number of set bits up to k.  (Rounding can make a row index
+// move by two in one sample when |dy| = 1 to the last bit; phase A counts its bits against the real
+// displacement and a wavefront that sees a difference walks that batch of beams with the literal
+// loop instead: s2_literal.)  The distance classes of slam/raycast.cpp:192-216 are thresholds on the
+// sample index, because d2_k = fl(fl(ex^2) + fl(ey^2)) is non-decreasing in k (x_k, y_k move
+// monotonically away from the origin and every rounding is monotone): k_far = first k with
+// !(d2_k < z2), k_vfar = first k with d2_k >= zmax2, found exactly by latching the position every 16
+// samples and re-walking the last 16.
+// Phase B, beams strictly in order, lane = sample, 64 samples per pass, integer work only: cell from
+// the bit counts (v_mbcnt), tile lookup, byte load; the loop-carried decisions of
+// slam/raycast.cpp:163-220 are scalar mask arithmetic.  The geometry of a whole ray is known before
+// its first byte arrives, so the loads of several passes are in flight together (a ray's cells are
+// distinct: none of them can be changed by the ray's own writes).
+// Afterwards, lane = beam again: the hit positions are re-walked (exact accumulated doubles) and
+// the beam likelihoods are added in beam order.
+#pragma once
+
+namespace slamk
+{
+enum { S2_NP = 4 };  // passes whose loads are in flight together
+
+// copy-on-write tiles with the table staged as a WINDOW of W x W tiles around the sensor origin
+// (every cell a ray can reach lies within max_iter cells of the start cell)
+struct TiledWin
+{
+    uint8_t* pool;
+    int32_t* tab;  // this particle's table in HBM
+    int32_t* win;  // LDS window: entry (a, b) = table entry of tile (ti0 + a, tj0 + b), 0 outside the canvas
+    int ti0, tj0, W, tcols;
+    const int32_t* freelist;
+    int* ctrl;
+    struct Cow
+    {
+        uint64_t wmask;
+        int e;
+        uint8_t* ptr;
+    };
+    __device__ __forceinline__ int slot(int i, int j) const { return ((i >> TILE_SHIFT) - ti0) * W + ((j >> TILE_SHIFT) - tj0); }
+    __device__ __forceinline__ uint8_t* cell_ptr(int e, int i, int j) const
+    {
+        return pool + (((size_t)(unsigned)(e & ~TILE_OWN) << 12) | (size_t)(unsigned)tile_cell(i, j));
+    }
+    // table entry of the tile of cell (i, j); lanes without a cell to read (ok == false) take entry 0 of the
+    // window: with it cell_ptr is a valid address whatever i and j are
+    __device__ __forceinline__ int entry(bool ok, int i, int j) const { return win[ok ? slot(i, j) : 0]; }
+    __device__ __forceinline__ bool owned(int e) const { return (e & TILE_OWN) != 0; }
+    // (rare once k_tile_plan has run) the lanes of `need` are about to write tiles their table does not own:
+    // one tile at a time is copied by the whole wavefront and the table repointed; e and ptr of the lanes
+    // that write it are updated.  A lane whose tile could not be allocated leaves the write mask.
+    __device__ __noinline__ Cow cow(uint64_t need, uint64_t wmask, int i, int j, int e, uint8_t* ptr, int lane) const
+    {
+        const bool mine = __builtin_amdgcn_inverse_ballot_w64(need);
+        const int t = mine ? slot(i, j) : -1;
+        uint64_t m = need;
+        while (m)
+        {
+            const int l = __builtin_ctzll(m);
+            const int tl = bcast_i32(t, l);
+            const int old = bcast_i32(e, l) & ~TILE_OWN;
+            const int tg = bcast_i32((i >> TILE_SHIFT) * tcols + (j >> TILE_SHIFT), l);
+            int nid = -1;
+            if (lane == 0)
+            {
+                const int pos = atomicAdd(&ctrl[0], 1);
+                if (pos < ctrl[1])
+                    nid = freelist[pos];
+                else
+                    ctrl[2] = 1;  // pool exhausted: the write is dropped, the host reports SLAM_ERR_NOMEM
+            }
+            nid = __builtin_amdgcn_readfirstlane(nid);
+            if (nid >= 0)
+            {
+                const uint4* from = reinterpret_cast<const uint4*>(pool + (size_t)old * TILE_BYTES);
+                uint4* to = reinterpret_cast<uint4*>(pool + (size_t)nid * TILE_BYTES);
+#pragma unroll
+                for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) to[q * 64 + lane] = from[q * 64 + lane];
+                if (lane == 0)
+                {
+                    tab[tg] = nid | TILE_OWN;
+                    win[tl] = nid | TILE_OWN;
+                }
+            }
+            const bool same = t == tl;
+            if (same && nid >= 0)
+            {
+                e = nid | TILE_OWN;
+                ptr = cell_ptr(e, i, j);
+            }
+            const uint64_t served = __ballot(same);
+            if (nid < 0) wmask &= ~served;
+            m &= ~served;
+        }
+        // the copies (and the table) before the cell stores and the next loads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return Cow{wmask, e, ptr};
+    }
+    // literal fallback only: one cell, every lane the same
+    __device__ __forceinline__ uint8_t load1(int i, int j) const { return *cell_ptr(win[slot(i, j)], i, j); }
+    __device__ __forceinline__ void store1(bool wr, int i, int j, uint8_t v, int lane) const
+    {
+        uint64_t w = __ballot(wr);
+        const int e = win[slot(i, j)];
+        uint8_t* ptr = cell_ptr(e, i, j);
+        const uint64_t need = w & __ballot(!owned(e));
+        if (need)
+        {
+            const Cow r = cow(need, w, i, j, e, ptr, lane);
+            w = r.wmask;
+            ptr = r.ptr;
+        }
+        if (__builtin_amdgcn_inverse_ballot_w64(w)) *ptr = v;
+    }
+};
+
+struct DenseS2
+{
+    uint8_t* base;
+    int cols;
+    struct Cow
+    {
+        uint64_t wmask;
+        int e;
+        uint8_t* ptr;
+    };
+    // bit 0 of the "entry": the lane has an in-bounds cell (any other lane reads the canvas's first byte)
+    __device__ __forceinline__ int entry(bool ok, int, int) const { return ok ? (TILE_OWN | 1) : TILE_OWN; }
+    __device__ __forceinline__ bool owned(int) const { return true; }
+    __device__ __forceinline__ uint8_t* cell_ptr(int e, int i, int j) const
+    {
+        return base + ((e & 1) ? (size_t)i * (size_t)cols + (size_t)j : (size_t)0);
+    }
+    __device__ __forceinline__ Cow cow(uint64_t, uint64_t wmask, int, int, int e, uint8_t* ptr, int) const { return Cow{wmask, e, ptr}; }
+    __device__ __forceinline__ uint8_t load1(int i, int j) const { return *cell_ptr(1, i, j); }
+    __device__ __forceinline__ void store1(bool wr, int i, int j, uint8_t v, int) const
+    {
+        if (wr) *cell_ptr(1, i, j) = v;
+    }
+};
+
+// One ray with the literal loop of slam/raycast.cpp:163-220, every lane computing the same values
+// (wave-uniform arguments), lane 0 storing.  Only for the batches phase A declares irregular.
+template <class MAP>
+__device__ __noinline__ void s2_literal(const MAP& map, int rows, int cols, double sx, double sy, double dx, double dy, double z2,
+                                        double zmax2, const uint8_t* lut_free, const uint8_t* lut_occ, int max_iter, int lane,
+                                        WaveRay* out)
+{
+    double x = sx, y = sy;
+    int i, j;
+    slam_cell_of(rows, x, y, &i, &j);
+    int pi = i, pj = j;
+    out->hx = -1.0;
+    out->hy = -1.0;
+    out->hcell = -1;
+    out->n_read = out->n_written = 0;
+    out->n_steps = 0;
+    bool drew = false, found = false;
+    for (int it = 0; it < max_iter && (!drew || !found); ++it)
+    {
+        x += dx;
+        y += dy;
+        out->n_steps++;
+        slam_cell_of(rows, x, y, &i, &j);
+        if (i == pi && j == pj) continue;
+        if (!slam_in_bounds(rows, cols, i, j)) break;
+        const uint8_t c = map.load1(i, j);
+        out->n_read++;
+        if (!found && c < 128)
+        {
+            out->hx = x;
+            out->hy = y;
+            out->hcell = i * cols + j;
+            found = true;
+        }
+        const double ex = x - sx, ey = y - sy;
+        const double d2 = ex * ex + ey * ey;
+        bool wr = false;
+        uint8_t v = 0;
+        if (d2 < z2)
+        {
+            wr = true;
+            v = lut_free[c];
+        }
+        else
+        {
+            if (!drew && z2 != zmax2)
+            {
+                wr = true;
+                v = lut_occ[c];
+            }
+            drew = true;
+        }
+        map.store1(wr && lane == 0, i, j, v, lane);
+        if (wr) out->n_written++;
+        if (d2 >= zmax2) break;
+        pi = i;
+        pj = j;
+    }
+}
+
+// lanes below f (f <= 0: none, f >= 64: all) / lanes at and above f; f wave-uniform
+__device__ __forceinline__ uint64_t s2_below(int f) { return f >= 64 ? ~0ull : (f <= 0 ? 0ull : ((1ull << f) - 1ull)); }
+__device__ __forceinline__ uint64_t s2_from(int f) { return ~s2_below(f); }
+__device__ __forceinline__ int s2_first(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
+
+// Phase B of one ray.  All ray-level values are wave-uniform.  Returns the sample number of the hit
+// (0: none); the hit cell follows from the hit position.
+template <class MAP>
+__device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bits + q, stride 64 per pass */, int rows, int cols,
+                                      int i0, int j0, int si, int sj, int k_far, int k_vfar, bool draw_occ, int max_iter,
+                                      const uint8_t* luts, int lane, unsigned* n_read, unsigned* n_written, unsigned* n_steps)
+{
+    const int npass = (max_iter + 63) / 64;
+    const int Lfar = k_far - 1, Lvfar = k_vfar - 1;  // as bit numbers: sample k is bit k - 1 of the ray
+    bool drew = false, found = false, done = false;
+    int base_r = 0, base_c = 0;  // row / column moves before the current pass
+    unsigned steps = (unsigned)max_iter, reads = 0, writes = 0;
+    int khit = 0;
+    for (int g = 0; g < npass && !done;)
+    {
+        // The ray cannot end before sample k_far (slam/raycast.cpp:163 needs `drew`) unless it leaves the
+        // grid: the first group of loads reaches a little beyond it (a ray usually ends at the first
+        // occupied cell behind the measured range); further passes one at a time.
+        int gn = g == 0 ? (Lfar + 24) / 64 + 1 : 1;
+        if (gn > S2_NP) gn = S2_NP;
+        if (gn > npass - g) gn = npass - g;
+        uint64_t cand[S2_NP], oob[S2_NP];
+        int ci[S2_NP], cj[S2_NP], ent[S2_NP];
+        uint8_t* ptr[S2_NP];
+        uint8_t cv[S2_NP];
+#pragma unroll
+        for (int u = 0; u < S2_NP; ++u)
+        {
+            if (u < gn)
+            {
+                const uint4 m = bits_q[(g + u) * 64];
+                const uint32_t r_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.x), r_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.y);
+                const uint32_t c_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.z), c_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.w);
+                const uint64_t R = ((uint64_t)r_hi << 32) | r_lo, C = ((uint64_t)c_hi << 32) | c_lo;
+                // moves up to and including this lane's sample (lane l = sample G0 + l + 1)
+                const int er = (int)__builtin_amdgcn_mbcnt_hi(r_hi, __builtin_amdgcn_mbcnt_lo(r_lo, 0)) + (__builtin_amdgcn_inverse_ballot_w64(R) ? 1 : 0);
+                const int ec = (int)__builtin_amdgcn_mbcnt_hi(c_hi, __builtin_amdgcn_mbcnt_lo(c_lo, 0)) + (__builtin_amdgcn_inverse_ballot_w64(C) ? 1 : 0);
+                const int i = __mul24(base_r + er, si) + i0, j = __mul24(base_c + ec, sj) + j0;
+                const uint64_t N = R | C;  // new cells (slam/raycast.cpp:171-174); phase A leaves no bits beyond max_iter
+                const uint64_t INB = __ballot(slam_in_bounds(rows, cols, i, j));
+                cand[u] = N & INB;
+                oob[u] = N & ~INB;
+                ci[u] = i;
+                cj[u] = j;
+                ent[u] = map.entry(__builtin_amdgcn_inverse_ballot_w64(cand[u]), i, j);
+                ptr[u] = map.cell_ptr(ent[u], i, j);
+                cv[u] = *ptr[u];
+                base_r += __builtin_popcountll(R);
+                base_c += __builtin_popcountll(C);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < S2_NP; ++u)
+        {
+            if (u < gn && !done)
+            {
+                const int G0 = (g + u) * 64;
+                const uint64_t OCC = __ballot(cv[u] < 128) & cand[u];
+                if (drew && oob[u] == 0 && G0 + 64 <= Lvfar)
+                {
+                    // behind the measured range, inside the grid and the sensor's range: the ray only looks for
+                    // its first occupied cell (found is false here, or the ray would have ended)
+                    uint64_t seen = cand[u];
+                    if (OCC)
+                    {
+                        const int f = __builtin_ctzll(OCC);
+                        khit = G0 + f + 1;
+                        steps = (unsigned)khit;
+                        seen &= s2_below(f + 1);
+                        done = true;
+                    }
+                    reads += (unsigned)__builtin_popcountll(seen);
+                    continue;
+                }
+                uint64_t W;         // lanes that write
+                uint64_t WOCC = 0;  // ... the occupied table (at most the one lane of slam/raycast.cpp:203-214)
+                if (G0 + 64 <= Lfar && oob[u] == 0)
+                {
+                    // every sample of the pass is nearer than z and in bounds: all new cells get the free update
+                    if (!found && OCC)
+                    {
+                        khit = G0 + __builtin_ctzll(OCC) + 1;
+                        found = true;
+                    }
+                    W = cand[u];
+                    reads += (unsigned)__builtin_popcountll(W);
+                }
+                else
+                {
+                    const uint64_t newx = cand[u] | oob[u];
+                    const int f_oob = s2_first(oob[u]);                                 // break before processing (:176)
+                    const int f_hit = found ? -1 : s2_first(OCC);                       // :183-189
+                    const int f_far = drew ? -1 : s2_first(newx & s2_from(Lfar - G0));  // :203-214
+                    const int f_vfar = G0 + 64 <= Lvfar ? 64 : s2_first(newx & s2_from(Lvfar - G0));  // break after processing (:216)
+                    const int both = f_hit > f_far ? f_hit : f_far;  // loop condition fails after this lane (:163)
+                    const int stop_incl = both < f_vfar ? both : f_vfar;
+                    const int term = stop_incl < f_oob ? stop_incl : f_oob;             // lane whose step ends the ray
+                    const int lim = stop_incl < (f_oob - 1) ? stop_incl : (f_oob - 1);  // last processed lane
+                    const uint64_t PROC = cand[u] & s2_below(lim + 1);
+                    if (!found && f_hit <= lim)
+                    {
+                        khit = G0 + f_hit + 1;
+                        found = true;
+                    }
+                    if (!drew && f_far <= lim)
+                    {
+                        drew = true;
+                        if (draw_occ) WOCC = 1ull << f_far;
+                    }
+                    W = (PROC & s2_below(Lfar - G0)) | WOCC;
+                    reads += (unsigned)__builtin_popcountll(PROC);
+                    if (term < 64)
+                    {
+                        steps = (unsigned)(G0 + term + 1);
+                        done = true;
+                    }
+                }
+                const uint8_t v = luts[(__builtin_amdgcn_inverse_ballot_w64(WOCC) ? 256 : 0) + cv[u]];
+                const uint64_t need = W & ~__ballot(map.owned(ent[u]));
+                uint8_t* to = ptr[u];
+                if (need)
+                {
+                    const typename MAP::Cow r = map.cow(need, W, ci[u], cj[u], ent[u], ptr[u], lane);
+                    W = r.wmask;
+                    to = r.ptr;
+                }
+                if (__builtin_amdgcn_inverse_ballot_w64(W)) *to = v;
+                writes += (unsigned)__builtin_popcountll(W);
+            }
+        }
+        g += gn;
+    }
+    *n_read += reads;
+    *n_written += writes;
+    *n_steps += steps;
+    return khit;
+}
+
+// LDS of one wavefront (dynamic): [512 B update tables][npass x 64 beams x 16 B geometry bits][win_w^2 x 4 B table window]
+template <bool TILED>
+__global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta, int npass, int win_w, int force_literal)
+{
+    extern __shared__ __align__(16) unsigned char s2_lds[];
+    uint8_t* luts = s2_lds;                                // free table, occupied table
+    uint4* bits = reinterpret_cast<uint4*>(s2_lds + 512);  // [npass][64 beams]: {R lo, R hi, C lo, C hi}
+    int32_t* win = reinterpret_cast<int32_t*>(s2_lds + 512 + (size_t)npass * 1024);
+    const int lane = threadIdx.x;
+    const int64_t p = blockIdx.x;
+    for (int t = lane; t < 512; t += 64) luts[t] = a.luts[t];
+    const double px = a.x[p], py = a.y[p], pth = a.th[p];
+    double s0, c0;
+    dm_sincos(pth + a.stheta, &s0, &c0);
+    const double sx = px + c0 * a.sd;
+    const double sy = py + s0 * a.sd;
+    const double rows_d = (double)a.rows;
+    int i0, j0;
+    slam_cell_of(a.rows, sx, sy, &i0, &j0);
+    const DenseS2 dmap = {a.grid + a.map_stride * (size_t)p, a.cols};
+    TiledWin tmap = {ta.pool, nullptr, win, 0, 0, win_w, ta.tcols, ta.freelist, ta.ctrl};
+    if (TILED)
+    {
+        tmap.tab = ta.tab + (size_t)p * ta.tiles_per_map;
+        // window origin: every reachable cell lies within max_iter cells of the start cell (a start far
+        // outside the canvas reaches nothing: clamped only to keep the arithmetic in range)
+        const int reach = npass * 64;
+        const int ci = i0 < -(1 << 24) ? -(1 << 24) : (i0 > (1 << 24) ? (1 << 24) : i0);
+        const int cj = j0 < -(1 << 24) ? -(1 << 24) : (j0 > (1 << 24) ? (1 << 24) : j0);
+        tmap.ti0 = (ci - reach) >> TILE_SHIFT;
+        tmap.tj0 = (cj - reach) >> TILE_SHIFT;
+        const int trows = ta.tiles_per_map / ta.tcols;
+        for (int t = lane; t < win_w * win_w; t += 64)
+        {
+            const int ti = tmap.ti0 + t / win_w, tj = tmap.tj0 + t % win_w;
+            win[t] = (ti >= 0 && tj >= 0 && ti < trows && tj < ta.tcols) ? tmap.tab[ti * ta.tcols + tj] : 0;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int max_iter = a.max_iter;
+    double acc = 0.0;
+    unsigned long long n_read = 0, n_written = 0, n_steps = 0;
+    for (int b0 = 0; b0 < a.B; b0 += 64)
+    {
+        const int b = b0 + lane;
+        const int cnt = (a.B - b0) < 64 ? (a.B - b0) : 64;
+        double dx = 0.0, dy = 0.0, z2 = 0.0;
+        if (b < a.B)
+        {
+            dm_sincos(pth + a.angles[b] + a.srot, &dy, &dx);
+            z2 = a.z2[b];
+        }
+        // ---- phase A: lane = beam ----
+        int k_far, k_vfar, si, sj;
+        bool regular;
+        double xl, yl;  // position at sample kl, the last multiple of 16 nearer than z: hits are usually behind it
+        int kl;
+        {
+            double x = sx, y = sy;
+            int pi = i0, pj = j0;
+            unsigned cnt_r = 0, cnt_c = 0;
+            double xf = sx, yf = sy, xv = sx, yv = sy;  // last latch with d2 < z2 / d2 < zmax2
+            int kf = 0, kv = 0;
+            for (int ps = 0; ps < npass; ++ps)
+            {
+                uint32_t w[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                {
+                    uint32_t rw = 0, cw = 0;
+#pragma unroll
+                    for (int s = 0; s < 32; ++s)
+                    {
+                        x += dx;
+                        y += dy;
+                        const int ni = slam_f2i((rows_d - y) - 1.0), nj = slam_f2i(x);
+                        rw |= (uint32_t)((ni - pi) & 1) << s;
+                        cw |= (uint32_t)((nj - pj) & 1) << s;
+                        pi = ni;
+                        pj = nj;
+                        if ((s & 15) == 15)
+                        {
+                            const double ex = x - sx, ey = y - sy;
+                            const double d2 = ex * ex + ey * ey;
+                            const int k = ps * 64 + h * 32 + s + 1;
+                            if (d2 < z2)
+                            {
+                                xf = x;
+                                yf = y;
+                                kf = k;
+                            }
+                            if (d2 < a.zmax2)
+                            {
+                                xv = x;
+                                yv = y;
+                                kv = k;
+                            }
+                        }
+                    }
+                    w[h] = rw;
+                    w[2 + h] = cw;
+                    cnt_r += (unsigned)__builtin_popcount(rw);
+                    cnt_c += (unsigned)__builtin_popcount(cw);
+                }
+                if (ps == npass - 1 && max_iter < npass * 64)
+                {  // samples beyond max_iter do not exist (they were walked for the check below only)
+                    const uint64_t keep = s2_below(max_iter - ps * 64);
+                    w[0] &= (uint32_t)keep;
+                    w[1] &= (uint32_t)(keep >> 32);
+                    w[2] &= (uint32_t)keep;
+                    w[3] &= (uint32_t)(keep >> 32);
+                }
+                bits[ps * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            // the recorded bits must add up to the real displacement (see the header comment)
+            const int di = pi - i0, dj = pj - j0;
+            regular = (unsigned)(di < 0 ? -di : di) == cnt_r && (unsigned)(dj < 0 ? -dj : dj) == cnt_c;
+            si = di > 0 ? 1 : (di < 0 ? -1 : 0);
+            sj = dj > 0 ? 1 : (dj < 0 ? -1 : 0);
+            // thresholds: the first sample at or beyond each distance lies within 16 samples of its latch
+            const int none = npass * 64 + 1;
+            k_far = none;
+            k_vfar = none;
+            xl = xf;
+            yl = yf;
+            kl = kf;
+#pragma unroll 4
+            for (int s = 1; s <= 16; ++s)
+            {
+                xf += dx;
+                yf += dy;
+                xv += dx;
+                yv += dy;
+                const double ex = xf - sx, ey = yf - sy;
+                if (!(ex * ex + ey * ey < z2) && k_far == none) k_far = kf + s;
+                const double fx = xv - sx, fy = yv - sy;
+                if (!(fx * fx + fy * fy < a.zmax2) && k_vfar == none) k_vfar = kv + s;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const bool literal = force_literal || __ballot(!regular && b < a.B) != 0;
+        // ---- phase B: beams in order, lane = sample ----
+        int my_khit = 0;
+        slam_ray_result mine = {-1.0, -1.0, -1};
+        for (int q = 0; q < cnt; ++q)
+        {
+            if (literal)
+            {
+                WaveRay wr;
+                if (TILED)
+                    s2_literal(tmap, a.rows, a.cols, sx, sy, bcast_f64(dx, q), bcast_f64(dy, q), bcast_f64(z2, q), a.zmax2, luts,
+                               luts + 256, max_iter, lane, &wr);
+                else
+                    s2_literal(dmap, a.rows, a.cols, sx, sy, bcast_f64(dx, q), bcast_f64(dy, q), bcast_f64(z2, q), a.zmax2, luts,
+                               luts + 256, max_iter, lane, &wr);
+                if (lane == q)
+                {
+                    mine.hx = wr.hx;
+                    mine.hy = wr.hy;
+                    mine.hcell = wr.hcell;
+                }
+                n_read += wr.n_read;
+                n_written += wr.n_written;
+                n_steps += wr.n_steps;
+            }
+            else
+            {
+                unsigned r = 0, w = 0, st = 0;
+                const bool draw_occ = bcast_f64(z2, q) != a.zmax2;  // slam/raycast.cpp:205
+                int khit;
+                if (TILED)
+                    khit = s2_ray(tmap, bits + q, a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
+                                  bcast_i32(k_vfar, q), draw_occ, max_iter, luts, lane, &r, &w, &st);
+                else
+                    khit = s2_ray(dmap, bits + q, a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
+                                  bcast_i32(k_vfar, q), draw_occ, max_iter, luts, lane, &r, &w, &st);
+                if (lane == q) my_khit = khit;
+                n_read += r;
+                n_written += w;
+                n_steps += st;
+            }
+            // the next ray of this wavefront must see these stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        // ---- lane = beam again: hit positions (exact accumulated doubles), likelihoods in beam order ----
+        if (!literal)
+        {
+            // re-walk to the hit sample from the latch behind it (or from the origin)
+            const bool from_latch = my_khit >= kl;
+            double hx = from_latch ? xl : sx, hy = from_latch ? yl : sy;
+            const int todo = my_khit - (from_latch ? kl : 0);
+            for (int k = 1; __ballot(k <= todo) != 0; ++k)
+                if (k <= todo)
+                {
+                    hx += dx;
+                    hy += dy;
+                }
+            if (my_khit > 0)
+            {
+                mine.hx = hx;
+                mine.hy = hy;
+                int hi, hj;
+                slam_cell_of(a.rows, hx, hy, &hi, &hj);
+                mine.hcell = hi * a.cols + hj;  // slam/raycast.cpp:183-189: the cell of the hit sample
+            }
+        }
+        double lw = 0.0;
+        if (b < a.B)
+        {
+            lw = slam_beam_logw(&mine, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
+            if (a.hit_xy)
+            {
+                const size_t o = (size_t)p * a.B + b;
+                a.hit_xy[2 * o] = mine.hx;
+                a.hit_xy[2 * o + 1] = mine.hy;
+                a.hit_cell[o] = mine.hcell;
+            }
+        }
+        for (int l = 0; l < cnt; ++l) acc += readlane_f64(lw, l);
+    }
+    if (lane == 0)
+    {
+        a.w[p] = a.log_domain ? acc : dm_exp(acc);
+        if (a.stats)
+        {
+            atomicAdd(&a.stats[0], n_read);
+            atomicAdd(&a.stats[1], n_written);
+            atomicAdd(&a.stats[2], n_steps);
+        }
+    }
+}
+}  // namespace slamk

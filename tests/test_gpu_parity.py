@@ -265,16 +265,23 @@ def test_weights_degenerate_underflow_and_tiny_ranges(sa):
 
 
 # ---- K2b SLAM mode: raycast + likelihood + occupancy update ---------------------------------------
-@pytest.mark.parametrize("shape", ["wave", "thread", "tiled"])
+S_SHAPES = {  # kernel shape -> (raycaster, canvas storage)
+    "wave": ("RAYCAST_FAST_BEAM_LANES", "MAPS_DENSE"), "thread": ("RAYCAST_FAST_PARTICLE_LANES", "MAPS_DENSE"),
+    "tiled": ("RAYCAST_FAST_BEAM_LANES", "MAPS_TILED"), "two_phase": ("RAYCAST_TWO_PHASE", "MAPS_DENSE"),
+    "two_phase_tiled": ("RAYCAST_TWO_PHASE", "MAPS_TILED"), "literal": ("RAYCAST_TWO_PHASE_LITERAL", "MAPS_DENSE"),
+    "literal_tiled": ("RAYCAST_TWO_PHASE_LITERAL", "MAPS_TILED"),
+}
+
+
+@pytest.mark.parametrize("shape", list(S_SHAPES))
 @pytest.mark.parametrize("B,zmax", [(90, 500.0), (130, 61.5)])
 def test_weights_slam_mode_maps_bit_exact(sa, shape, B, zmax):
     rng = np.random.default_rng(21)
     N, rows, cols = 48, 300, 400
     free = orc.load_map("map")
     ang, dist = orc.make_scan(free, [400.0, 400.0, np.pi / 90], OFFSET, B, max_dist=zmax)
-    f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM,
-                  raycaster=sa.capi.RAYCAST_FAST_PARTICLE_LANES if shape == "thread" else sa.capi.RAYCAST_FAST_BEAM_LANES,
-                  map_storage=sa.capi.MAPS_TILED if shape == "tiled" else sa.capi.MAPS_DENSE)
+    f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, raycaster=getattr(sa.capi, S_SHAPES[shape][0]),
+                  map_storage=getattr(sa.capi, S_SHAPES[shape][1]))
     x, y, th = cloud(rng, N, cols / 2, rows / 2, sxy=6.0, sth=0.3, th0=np.pi / 2)
     x[:3], y[:3] = [2.5, cols - 1.5, -20.0], [rows - 2.5, 1.5, 100.0]   # at the canvas border / outside
     x[3:6], y[3:6] = [3e9, -1e15, 150.0], [10.0, 20.0, -(2.0 ** 40)]   # far outside, beyond int range

@@ -23,11 +23,13 @@ capi.check(capi.load_library().slam_fake_lidar_scan(0, capi.ptr(m01), m01.shape[
 ang = np.arange(B) * (2 * np.pi / B) - np.pi
 scans = [(ang, np.where(hits[k, :, 0] != -1, np.hypot(hits[k, :, 1] - sp[k, 1], hits[k, :, 0] - sp[k, 0]), 500.0)) for k in range(len(poses))]
 CR = int(os.environ.get("SB_ROWS", C))
-variants = [("wave", capi.RAYCAST_FAST_BEAM_LANES, capi.MAPS_DENSE), ("tiled", capi.RAYCAST_FAST, capi.MAPS_TILED)]  # dense is asked for explicitly: tiles are the default
+variants = [("wave", capi.RAYCAST_FAST_BEAM_LANES, capi.MAPS_DENSE), ("dense2", capi.RAYCAST_TWO_PHASE, capi.MAPS_DENSE),
+            ("tiled_old", capi.RAYCAST_FAST_BEAM_LANES, capi.MAPS_TILED),
+            ("tiled", capi.RAYCAST_FAST, capi.MAPS_TILED)]  # dense is asked for explicitly: tiles + the two-phase kernel are the default
 if os.environ.get("SB_THREAD", "0") == "1":
     variants.append(("thread", capi.RAYCAST_FAST_PARTICLE_LANES, capi.MAPS_DENSE))
 if os.environ.get("SB_ONLY"):
-    variants = [v for v in variants if v[0] == os.environ["SB_ONLY"]]
+    variants = [v for v in variants if v[0] in os.environ["SB_ONLY"].split(",")]
 if os.environ.get("SB_ONLY") == "shard":
     # one tiled shard driven through slam_amd.dist (world 1): select, sparse pack (tables + distinct tiles), import
     import torch
@@ -60,6 +62,10 @@ for name, rc, storage in variants:
     f.synchronize()
     dt = (time.perf_counter() - t0) / (len(scans) - 4) * 1e3
     km = f.kernel_ms(); st = f.stats()
+    if storage == capi.MAPS_TILED:  # one more step in two halves: tiles copied by one weighting pass
+        f.predict(odom, alphas); f.update_weights(*scans[-1], 5.0, 500.0, bench.OFFSET)
+        print("   tiles copied by one weighting pass:", f.tile_stats()["allocated_since"], flush=True)
+        f.resample(); f.kernel_ms()
     print(f"{name:7s} N={N} canvas={CR}x{C}: {dt:8.3f} ms/step wall;", {k: round(v[0] / max(v[1], 1), 3) for k, v in km.items()},
           f"cells_read/ray={st['cells_read'] / (N * B):.1f} written/ray={st['cells_written'] / (N * B):.1f}",
           f.tile_stats() if storage == capi.MAPS_TILED else "", flush=True)

@@ -19,7 +19,9 @@ while time.time() - t0 < budget:
     mk = lambda **kw: sa.Filter(N, rows, cols, mode=capi.MODE_SLAM, seed=seed, **kw)
     fs = {"wave": mk(raycaster=capi.RAYCAST_FAST_BEAM_LANES, map_storage=capi.MAPS_DENSE),
           "thread": mk(raycaster=capi.RAYCAST_FAST_PARTICLE_LANES, map_storage=capi.MAPS_DENSE),
-          "tiled": mk(map_storage=capi.MAPS_TILED, tile_pool_tiles=pool)}
+          "tiled": mk(map_storage=capi.MAPS_TILED, tile_pool_tiles=pool),
+          "tiled_old": mk(raycaster=capi.RAYCAST_FAST_BEAM_LANES, map_storage=capi.MAPS_TILED, tile_pool_tiles=pool),
+          "dense2": mk(raycaster=capi.RAYCAST_TWO_PHASE, map_storage=capi.MAPS_DENSE)}
     x = cols / 2 + rng.choice([1.0, 30.0, 400.0]) * rng.standard_normal(N); y = rows / 2 + rng.choice([1.0, 30.0]) * rng.standard_normal(N)
     th = rng.uniform(-3, 3, N)
     for f in fs.values():
@@ -34,7 +36,7 @@ while time.time() - t0 < budget:
                 pass
             f.update(ang, dist, 5.0, zmax, off)
         ref = fs["wave"]
-        for name in ("thread", "tiled"):
+        for name in ("thread", "tiled", "tiled_old", "dense2"):
             f = fs[name]
             ok = np.array_equal(f.last_indices(), ref.last_indices()) and np.array_equal(f.weights().view(np.uint64), ref.weights().view(np.uint64))
             for p in rng.choice(N, 4, replace=False):
