@@ -262,6 +262,27 @@ int slam_raycast_u8(int32_t device, const uint8_t* map, int32_t rows, int32_t co
 int slam_raycast_batch(int32_t device, int32_t kind, const uint8_t* map, int32_t rows, int32_t cols, const double* poses3,
                        int64_t n, double max_distance_squared, double step_size, double* hits_xy);
 
+/* Resident single-map handle for the raycasts above (and for raycast_mapping on ONE canvas): the grid
+ * is uploaded once (slam_map_create / slam_map_upload), every call afterwards costs one small upload
+ * of the rays, one launch and one small download.  The three stateless calls above are one-shot
+ * wrappers over it.  FakeLidar::scan / raycast<T> of the C++ shim keep a handle per map
+ * (slam/fake_lidar.cpp:15-33, slam/raycast.cpp:7-141). */
+typedef struct slam_map slam_map;
+int slam_map_create(int32_t device, const uint8_t* map, int32_t rows, int32_t cols, slam_map** out);
+void slam_map_destroy(slam_map* m);
+int slam_map_upload(slam_map* m, const uint8_t* map);    /* replace the grid (same size) */
+int slam_map_download(slam_map* m, uint8_t* map);        /* the grid as slam_map_raycast_mapping left it */
+int slam_map_fake_lidar_scan(slam_map* m, const double* poses3, int32_t n_poses, double start, double stop, double max_dist,
+                             int32_t n_rays, double* hits_xy);
+int slam_map_raycast_batch(slam_map* m, int32_t kind, const double* poses3, int64_t n, double max_distance_squared,
+                           double step_size, double* hits_xy);
+/* slam::raycast_mapping (slam/raycast.cpp:143-223) for n rays (x, y, theta; measured range squared
+ * z_squared[k] <= z_max_squared) applied IN ORDER to the resident uint8 canvas: hit search and
+ * occupancy update exactly as the filter's own kernels do them; hits_xy[2k..] = hit or (-1,-1).
+ * measurement_model_beam (slam/raycast.cpp:225-242) is this plus two host scalars (the shim). */
+int slam_map_raycast_mapping(slam_map* m, const double* poses3, const double* z_squared, int64_t n, double z_max_squared,
+                             double step_size, double* hits_xy);
+
 /* The one entry point that allocates nothing.  It has NO counterpart in the reference; it exists for
  * callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses
  * that forbid allocation.  It is the selection half of slam_mcl_resample (slam/mcl.cpp:157-203: running

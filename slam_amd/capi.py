@@ -114,6 +114,13 @@ SYMBOLS = {
     "slam_fake_lidar_scan": (ctypes.c_int, [_I32, _P, _I32, _I32, _P, _I32, _D, _D, _D, _I32, _P]),
     "slam_raycast_u8": (ctypes.c_int, [_I32, _P, _I32, _I32, _P, _I64, _D, _D, _P]),
     "slam_raycast_batch": (ctypes.c_int, [_I32, _I32, _P, _I32, _I32, _P, _I64, _D, _D, _P]),
+    "slam_map_create": (ctypes.c_int, [_I32, _P, _I32, _I32, ctypes.POINTER(_P)]),
+    "slam_map_destroy": (None, [_P]),
+    "slam_map_upload": (ctypes.c_int, [_P, _P]),
+    "slam_map_download": (ctypes.c_int, [_P, _P]),
+    "slam_map_fake_lidar_scan": (ctypes.c_int, [_P, _P, _I32, _D, _D, _D, _I32, _P]),
+    "slam_map_raycast_batch": (ctypes.c_int, [_P, _I32, _P, _I64, _D, _D, _P]),
+    "slam_map_raycast_mapping": (ctypes.c_int, [_P, _P, _P, _I64, _D, _D, _P]),
     "slam_static_init": (ctypes.c_int, [_I32]),
     "slam_resample_select_static": (ctypes.c_int, [_I32, _P, _P, _I64, _I32, _P, ctypes.c_uint64, ctypes.c_uint64, _P]),
 }

@@ -1434,6 +1434,26 @@ __global__ void __launch_bounds__(256) k_raycast_ro(const uint8_t* map, int rows
     hits[2 * r + 1] = hy;
 }
 
+
+// slam::raycast_mapping (slam/raycast.cpp:143-223) for n rays applied IN ORDER to one canvas: the
+// single-particle form behind the shim's raycast_mapping / measurement_model_beam.  One lane walks
+// (the rays of one canvas depend on each other through it); hits[2k..] = hit position or (-1, -1).
+__global__ void __launch_bounds__(64) k_raycast_mapping_seq(uint8_t* map, int rows, int cols, int64_t n, const double* px,
+                                                            const double* py, const double* pth, const double* z2, double zmax2,
+                                                            double step, int max_iter, const uint8_t* luts, double* hits)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    for (int64_t r = 0; r < n; ++r)
+    {
+        double s, c;
+        dm_sincos(pth[r], &s, &c);
+        slam_ray_result res;
+        ray_walk<true, false>(map, rows, cols, px[r], py[r], step * c, step * s, z2[r], zmax2, luts, luts + 256, max_iter, &res,
+                              nullptr);
+        hits[2 * r] = res.hx;
+        hits[2 * r + 1] = res.hy;
+    }
+}
 }  // namespace slamk
 
 #include "slam_s2.h"

@@ -1552,103 +1552,248 @@ SLAM_API int slam_mcl_device_state_get(slam_mcl* h, slam_mcl_device_state* out)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Resident map for the single-map raycasts (slam/raycast.cpp:7-223, slam/fake_lidar.cpp:15-33): the
+// grid is uploaded once, every call then costs one small upload of the rays, one launch and one small
+// download.  The stateless entry points below are one-shot wrappers over it.
+struct slam_map
+{
+    int device = 0;
+    int rows = 0, cols = 0;
+    uint8_t* grid = nullptr;
+    uint8_t* luts = nullptr;   // update tables (slam_map_raycast_mapping)
+    double* rays = nullptr;    // [x | y | theta | z2 | hit x, hit y], grown on demand
+    int64_t ray_cap = 0;
+    double* pin = nullptr;     // pinned staging of the same size
+    hipStream_t stream = nullptr;
+};
+
 namespace
 {
-template <int KIND>
-int raycast_batch(int device, const uint8_t* map, int rows, int cols, const std::vector<double>& px,
-                  const std::vector<double>& py, const std::vector<double>& pth, double max2, double step, double* hits)
+int map_reserve(slam_map* m, int64_t n)
 {
-    const int64_t n = (int64_t)px.size();
-    int ndev = 0;
-    HIPCHK(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(SLAM_ERR_ARG, "device ordinal out of range");
-    HIPCHK(hipSetDevice(device));
-    if (!map || rows <= 0 || cols <= 0 || !hits || !(step > 0) || !(max2 >= 0) || !std::isfinite(max2))
+    if (n <= m->ray_cap) return SLAM_OK;
+    if (m->rays) hipFree(m->rays);
+    if (m->pin) hipHostFree(m->pin);
+    m->rays = nullptr;
+    m->pin = nullptr;
+    m->ray_cap = 0;
+    const int64_t cap = n < 1024 ? 1024 : n;
+    int rc = dev_alloc(&m->rays, 6 * (size_t)cap);
+    if (rc) return rc;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&m->pin), sizeof(double) * 6 * (size_t)cap, hipHostMallocDefault));
+    m->ray_cap = cap;
+    return SLAM_OK;
+}
+
+int check_map(slam_map* m)
+{
+    if (!m) return fail(SLAM_ERR_ARG, "null map handle");
+    hipError_t e = hipSetDevice(m->device);
+    if (e != hipSuccess) return fail(SLAM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return SLAM_OK;
+}
+
+// rays: n x (x, y, theta) given by fill(k, &x, &y, &theta); z2 optional; kind 1 / 2: read-only, 3: raycast_mapping
+template <class FILL>
+int map_cast(slam_map* m, int kind, int64_t n, FILL fill, const double* z2, double max2, double step, double* hits)
+{
+    if (n <= 0 || !hits || !(step > 0) || !std::isfinite(step) || !(max2 >= 0) || !std::isfinite(max2))
         return fail(SLAM_ERR_ARG, "raycast: bad argument");
+    int rc = map_reserve(m, n);
+    if (rc) return rc;
+    double *px = m->pin, *py = m->pin + n, *pth = m->pin + 2 * n, *pz = m->pin + 3 * n;
     for (int64_t k = 0; k < n; ++k)
-        if (!std::isfinite(px[k]) || !std::isfinite(py[k]) || !std::isfinite(pth[k])) return fail(SLAM_ERR_ARG, "raycast: non-finite pose");
-    uint8_t* dmap = nullptr;
-    double *dx = nullptr, *dy = nullptr, *dth = nullptr, *dh = nullptr;
-    int rc = SLAM_OK;
-    if ((rc = dev_alloc(&dmap, (size_t)rows * cols)) || (rc = dev_alloc(&dx, n)) || (rc = dev_alloc(&dy, n)) ||
-        (rc = dev_alloc(&dth, n)) || (rc = dev_alloc(&dh, 2 * n)))
     {
-        hipFree(dmap); hipFree(dx); hipFree(dy); hipFree(dth); hipFree(dh);
-        return rc;
+        fill(k, &px[k], &py[k], &pth[k]);
+        pz[k] = z2 ? z2[k] : 0.0;
+        if (!std::isfinite(px[k]) || !std::isfinite(py[k]) || !std::isfinite(pth[k]) || !std::isfinite(pz[k]) || pz[k] < 0 ||
+            pz[k] > max2)
+            return fail(SLAM_ERR_ARG, "raycast: non-finite pose, or a range outside [0, max]");
     }
-    hipError_t e = hipMemcpy(dmap, map, (size_t)rows * cols, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dx, px.data(), sizeof(double) * n, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dy, py.data(), sizeof(double) * n, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dth, pth.data(), sizeof(double) * n, hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-    {
-        const double reach = std::fmin(std::sqrt(max2) / step, 1.0e8);
-        const int max_iter = (int)std::ceil(reach) + 8;
-        hipLaunchKernelGGL(slamk::k_raycast_ro<KIND>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, 0, dmap, rows, cols, n,
-                           dx, dy, dth, max2, step, max_iter, dh);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(hits, dh, sizeof(double) * 2 * n, hipMemcpyDeviceToHost);
-    hipFree(dmap); hipFree(dx); hipFree(dy); hipFree(dth); hipFree(dh);
-    if (e != hipSuccess) return fail(SLAM_ERR_HIP, std::string("raycast batch: ") + hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(m->rays, m->pin, sizeof(double) * 4 * (size_t)n, hipMemcpyHostToDevice, m->stream));
+    double* dh = m->rays + 4 * n;
+    const double reach = std::fmin(std::sqrt(max2) / step, 1.0e8);
+    const int max_iter = (int)std::ceil(reach) + 8;
+    if (kind == 1)
+        hipLaunchKernelGGL(slamk::k_raycast_ro<1>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, m->stream, m->grid, m->rows, m->cols, n,
+                           m->rays, m->rays + n, m->rays + 2 * n, max2, step, max_iter, dh);
+    else if (kind == 2)
+        hipLaunchKernelGGL(slamk::k_raycast_ro<2>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, m->stream, m->grid, m->rows, m->cols, n,
+                           m->rays, m->rays + n, m->rays + 2 * n, max2, step, max_iter, dh);
+    else
+        hipLaunchKernelGGL(slamk::k_raycast_mapping_seq, dim3(1), dim3(64), 0, m->stream, m->grid, m->rows, m->cols, n, m->rays,
+                           m->rays + n, m->rays + 2 * n, m->rays + 3 * n, max2, step, max_iter, m->luts, dh);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(m->pin + 4 * n, dh, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    std::memcpy(hits, m->pin + 4 * n, sizeof(double) * 2 * (size_t)n);
     return SLAM_OK;
 }
 }  // namespace
 
-SLAM_API int slam_fake_lidar_scan(int32_t device, const uint8_t* map01, int32_t rows, int32_t cols, const double* poses3,
-                                  int32_t n_poses, double start, double stop, double max_dist, int32_t n_rays,
-                                  double* hits_xy)
+SLAM_API void slam_map_destroy(slam_map* m)
 {
-    if (!poses3 || n_poses <= 0 || n_rays <= 0) return fail(SLAM_ERR_ARG, "fake_lidar_scan: bad argument");
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    if (m->grid) hipFree(m->grid);
+    if (m->luts) hipFree(m->luts);
+    if (m->rays) hipFree(m->rays);
+    if (m->pin) hipHostFree(m->pin);
+    if (m->stream) hipStreamDestroy(m->stream);
+    delete m;
+}
+
+SLAM_API int slam_map_upload(slam_map* m, const uint8_t* map)
+{
+    int rc = check_map(m);
+    if (rc) return rc;
+    if (!map) return fail(SLAM_ERR_ARG, "map_upload: null");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(m->grid, map, (size_t)m->rows * m->cols, hipMemcpyHostToDevice));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_map_download(slam_map* m, uint8_t* map)
+{
+    int rc = check_map(m);
+    if (rc) return rc;
+    if (!map) return fail(SLAM_ERR_ARG, "map_download: null");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(map, m->grid, (size_t)m->rows * m->cols, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+SLAM_API int slam_map_create(int32_t device, const uint8_t* map, int32_t rows, int32_t cols, slam_map** out)
+{
+    if (!out) return fail(SLAM_ERR_ARG, "map_create: null out");
+    *out = nullptr;
+    if (!map || rows <= 0 || cols <= 0 || rows > (1 << 20) || cols > (1 << 20) || (int64_t)rows * cols >= 2147483647LL)
+        return fail(SLAM_ERR_ARG, "map_create: null map or rows/cols out of range");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(SLAM_ERR_ARG, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    slam_map* m = new (std::nothrow) slam_map();
+    if (!m) return fail(SLAM_ERR_NOMEM, "host allocation failed");
+    m->device = device;
+    m->rows = rows;
+    m->cols = cols;
+    int rc = dev_alloc(&m->grid, (size_t)rows * cols);
+    if (!rc) rc = dev_alloc(&m->luts, 512);
+    if (!rc && hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(SLAM_ERR_HIP, "hipStreamCreate");
+    if (!rc)
+    {
+        uint8_t t[512];
+        build_luts(t);
+        if (hipMemcpy(m->luts, t, 512, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SLAM_ERR_HIP, "lut upload");
+    }
+    if (!rc) rc = slam_map_upload(m, map);
+    if (rc)
+    {
+        std::string keep = g_err;
+        slam_map_destroy(m);
+        g_err = keep;
+        return rc;
+    }
+    *out = m;
+    return SLAM_OK;
+}
+
+SLAM_API int slam_map_fake_lidar_scan(slam_map* m, const double* poses3, int32_t n_poses, double start, double stop, double max_dist,
+                                      int32_t n_rays, double* hits_xy)
+{
+    int rc = check_map(m);
+    if (rc) return rc;
+    if (!poses3 || n_poses <= 0 || n_rays <= 0 || !std::isfinite(start) || !std::isfinite(stop) || !std::isfinite(max_dist))
+        return fail(SLAM_ERR_ARG, "fake_lidar_scan: bad argument");
     // slam/fake_lidar.cpp:17-30: theta starts at pose.theta - range/2 and ACCUMULATES by += step
     const double range = stop - start;
     const double step = range / n_rays;
-    const size_t n = (size_t)n_poses * n_rays;
-    std::vector<double> px(n), py(n), pth(n);
+    std::vector<double> th((size_t)n_poses * n_rays);
     for (int p = 0; p < n_poses; ++p)
     {
         double theta = poses3[3 * p + 2];
         theta -= range / 2;
         for (int r = 0; r < n_rays; ++r)
         {
-            px[(size_t)p * n_rays + r] = poses3[3 * p];
-            py[(size_t)p * n_rays + r] = poses3[3 * p + 1];
-            pth[(size_t)p * n_rays + r] = theta;
+            th[(size_t)p * n_rays + r] = theta;
             theta += step;
         }
     }
-    return raycast_batch<2>(device, map01, rows, cols, px, py, pth, max_dist * max_dist, 0.5, hits_xy);
+    auto fill = [&](int64_t k, double* x, double* y, double* t) {
+        const int64_t p = k / n_rays;
+        *x = poses3[3 * p];
+        *y = poses3[3 * p + 1];
+        *t = th[(size_t)k];
+    };
+    return map_cast(m, 2, (int64_t)n_poses * n_rays, fill, nullptr, max_dist * max_dist, 0.5, hits_xy);
+}
+
+SLAM_API int slam_map_raycast_batch(slam_map* m, int32_t kind, const double* poses3, int64_t n, double max_distance_squared,
+                                    double step_size, double* hits_xy)
+{
+    int rc = check_map(m);
+    if (rc) return rc;
+    if (!poses3 || n <= 0 || (kind != 1 && kind != 2)) return fail(SLAM_ERR_ARG, "raycast_batch: bad argument");
+    auto fill = [&](int64_t k, double* x, double* y, double* t) {
+        *x = poses3[3 * k];
+        *y = poses3[3 * k + 1];
+        *t = poses3[3 * k + 2];
+    };
+    return map_cast(m, kind, n, fill, nullptr, max_distance_squared, step_size, hits_xy);
+}
+
+SLAM_API int slam_map_raycast_mapping(slam_map* m, const double* poses3, const double* z_squared, int64_t n, double z_max_squared,
+                                      double step_size, double* hits_xy)
+{
+    int rc = check_map(m);
+    if (rc) return rc;
+    if (!poses3 || !z_squared || n <= 0) return fail(SLAM_ERR_ARG, "raycast_mapping: bad argument");
+    auto fill = [&](int64_t k, double* x, double* y, double* t) {
+        *x = poses3[3 * k];
+        *y = poses3[3 * k + 1];
+        *t = poses3[3 * k + 2];
+    };
+    return map_cast(m, 3, n, fill, z_squared, z_max_squared, step_size, hits_xy);
+}
+
+namespace
+{
+struct TempMap
+{
+    slam_map* m = nullptr;
+    ~TempMap() { slam_map_destroy(m); }
+};
+}  // namespace
+
+SLAM_API int slam_fake_lidar_scan(int32_t device, const uint8_t* map01, int32_t rows, int32_t cols, const double* poses3,
+                                  int32_t n_poses, double start, double stop, double max_dist, int32_t n_rays,
+                                  double* hits_xy)
+{
+    TempMap t;
+    int rc = slam_map_create(device, map01, rows, cols, &t.m);
+    if (rc) return rc;
+    return slam_map_fake_lidar_scan(t.m, poses3, n_poses, start, stop, max_dist, n_rays, hits_xy);
 }
 
 SLAM_API int slam_raycast_u8(int32_t device, const uint8_t* map, int32_t rows, int32_t cols, const double* poses3,
                              int64_t n, double max_distance_squared, double step_size, double* hits_xy)
 {
-    if (!poses3 || n <= 0) return fail(SLAM_ERR_ARG, "raycast_u8: bad argument");
-    std::vector<double> px(n), py(n), pth(n);
-    for (int64_t k = 0; k < n; ++k)
-    {
-        px[k] = poses3[3 * k];
-        py[k] = poses3[3 * k + 1];
-        pth[k] = poses3[3 * k + 2];
-    }
-    return raycast_batch<1>(device, map, rows, cols, px, py, pth, max_distance_squared, step_size, hits_xy);
+    TempMap t;
+    int rc = slam_map_create(device, map, rows, cols, &t.m);
+    if (rc) return rc;
+    return slam_map_raycast_batch(t.m, 1, poses3, n, max_distance_squared, step_size, hits_xy);
 }
 
 SLAM_API int slam_raycast_batch(int32_t device, int32_t kind, const uint8_t* map, int32_t rows, int32_t cols,
                                 const double* poses3, int64_t n, double max_distance_squared, double step_size,
                                 double* hits_xy)
 {
-    if (!poses3 || n <= 0 || (kind != 1 && kind != 2)) return fail(SLAM_ERR_ARG, "raycast_batch: bad argument");
-    std::vector<double> px(n), py(n), pth(n);
-    for (int64_t k = 0; k < n; ++k)
-    {
-        px[k] = poses3[3 * k];
-        py[k] = poses3[3 * k + 1];
-        pth[k] = poses3[3 * k + 2];
-    }
-    return kind == 1 ? raycast_batch<1>(device, map, rows, cols, px, py, pth, max_distance_squared, step_size, hits_xy)
-                     : raycast_batch<2>(device, map, rows, cols, px, py, pth, max_distance_squared, step_size, hits_xy);
+    TempMap t;
+    int rc = slam_map_create(device, map, rows, cols, &t.m);
+    if (rc) return rc;
+    return slam_map_raycast_batch(t.m, kind, poses3, n, max_distance_squared, step_size, hits_xy);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -5,9 +5,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../../include/slam_hip.h"
 #include "../include/slam/fake_lidar.h"
@@ -107,6 +109,7 @@ Pose MCL::sensor_position(const Pose& frame_position, const Pose& scanner_offset
     return ret;
 }
 
+#ifndef SLAM_SHIM_REFERENCE_UTIL  // inside the reference's tree its own util.cpp defines these
 // ---- caller-side helpers (single pose, host) -------------------------------------------------------
 double normalize_angle(double angle)
 {
@@ -150,6 +153,8 @@ double sample_triangular_distribution(double stddev)
     return std::sqrt(6) / 2 * first + distribution(generator);
 }
 
+#endif
+
 Pose sample_motion_model_odometry(const Odometry& odom, const Pose& pose, std::array<double, 4> alphas)
 {
     // slam/motion.cpp:9-32 for ONE pose (the ground-truth robot of the callers), noise as in slam/util.cpp:27-34
@@ -175,6 +180,7 @@ Pose sample_motion_model_velocity(const Velocity& vel, const Pose& pose, double 
             normalize_angle(pose.theta + w * dt + gamma * dt)};
 }
 
+#ifndef SLAM_SHIM_REFERENCE_UTIL
 Pose average_pose(const std::vector<Particle>& particles)
 {
     double ax = 0, ay = 0, tx = 0, ty = 0;
@@ -188,16 +194,60 @@ Pose average_pose(const std::vector<Particle>& particles)
     return {ax / particles.size(), ay / particles.size(), std::atan2(ty, tx)};
 }
 
-// ---- scan synthesis and read-only raycasts on the GPU --------------------------------------------------
+#endif
+
+// ---- scan synthesis and raycasts on the GPU -------------------------------------------------------------
+namespace
+{
+int shim_device() { return std::getenv("SLAM_DEVICE") ? std::atoi(std::getenv("SLAM_DEVICE")) : 0; }
+
+// One resident grid per source cv::Mat: the converted bytes are uploaded when the handle is made and
+// again only when the caller's matrix has changed (exact comparison against a host copy: a 4 MB memcmp
+// is far cheaper than the conversion, the allocation and the upload it saves).
+struct MapCache
+{
+    const void* key = nullptr;
+    int rows = 0, cols = 0, elem = 0, kind = 0;
+    std::vector<unsigned char> source;  // the caller's bytes at upload time
+    slam_map* map = nullptr;
+    ~MapCache() { slam_map_destroy(map); }
+};
+
+template <class T, class F>
+slam_map* resident(MapCache& c, const cv::Mat& m, int kind, F to_u8)
+{
+    const size_t n = static_cast<size_t>(m.rows) * m.cols;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(&m.at<T>(0, 0));
+    const bool same_shape = c.map && c.rows == m.rows && c.cols == m.cols && c.elem == (int)sizeof(T) && c.kind == kind;
+    if (same_shape && c.source.size() == n * sizeof(T) && std::memcmp(c.source.data(), src, n * sizeof(T)) == 0) return c.map;
+    std::vector<uint8_t> u8(n);
+    for (int i = 0; i < m.rows; ++i)
+        for (int j = 0; j < m.cols; ++j) u8[static_cast<size_t>(i) * m.cols + j] = to_u8(m.at<T>(i, j));
+    if (same_shape)
+        check(slam_map_upload(c.map, u8.data()), "slam_map_upload");
+    else
+    {
+        slam_map_destroy(c.map);
+        c.map = nullptr;
+        check(slam_map_create(shim_device(), u8.data(), m.rows, m.cols, &c.map), "slam_map_create");
+    }
+    c.rows = m.rows;
+    c.cols = m.cols;
+    c.elem = sizeof(T);
+    c.kind = kind;
+    c.source.assign(src, src + n * sizeof(T));
+    return c.map;
+}
+
+thread_local MapCache g_lidar_map, g_raycast_map[3];
+}  // namespace
+
 std::vector<Pose> FakeLidar::scan(const cv::Mat& map, const Pose& pose) const
 {
-    std::vector<uint8_t> m01(static_cast<size_t>(map.rows) * map.cols);
-    for (int i = 0; i < map.rows; ++i)
-        for (int j = 0; j < map.cols; ++j) m01[static_cast<size_t>(i) * map.cols + j] = map.at<int>(i, j) ? 1 : 0;
+    slam_map* m = resident<int>(g_lidar_map, map, 2, [](int v) { return static_cast<uint8_t>(v ? 1 : 0); });
     const double p3[3] = {pose.x, pose.y, pose.theta};
     std::vector<double> hits(2 * static_cast<size_t>(n_rays));
-    check(slam_fake_lidar_scan(0, m01.data(), map.rows, map.cols, p3, 1, start, stop, max_dist, n_rays, hits.data()),
-          "slam_fake_lidar_scan");
+    check(slam_map_fake_lidar_scan(m, p3, 1, start, stop, max_dist, n_rays, hits.data()), "slam_map_fake_lidar_scan");
     // slam/fake_lidar.cpp:23-30: every returned pose carries the ray's own angle
     const double range = stop - start, step = range / n_rays;
     std::vector<Pose> out(n_rays);
@@ -214,14 +264,12 @@ std::vector<Pose> FakeLidar::scan(const cv::Mat& map, const Pose& pose) const
 namespace
 {
 template <class T, class F>
-Pose raycast_one(const cv::Mat& map, const Pose& pose, double max2, double step, int kind, F to_u8)
+Pose raycast_one(MapCache& c, const cv::Mat& map, const Pose& pose, double max2, double step, int kind, F to_u8)
 {
-    std::vector<uint8_t> m(static_cast<size_t>(map.rows) * map.cols);
-    for (int i = 0; i < map.rows; ++i)
-        for (int j = 0; j < map.cols; ++j) m[static_cast<size_t>(i) * map.cols + j] = to_u8(map.at<T>(i, j));
+    slam_map* m = resident<T>(c, map, kind, to_u8);
     const double p3[3] = {pose.x, pose.y, pose.theta};
     double hit[2];
-    check(slam_raycast_batch(0, kind, m.data(), map.rows, map.cols, p3, 1, max2, step, hit), "slam_raycast_batch");
+    check(slam_map_raycast_batch(m, kind, p3, 1, max2, step, hit), "slam_map_raycast_batch");
     return {hit[0], hit[1], pose.theta};
 }
 }  // namespace
@@ -229,16 +277,47 @@ Pose raycast_one(const cv::Mat& map, const Pose& pose, double max2, double step,
 template <>
 Pose raycast<unsigned char>(const cv::Mat& map, const Pose& pose, double max2, double step)
 {
-    return raycast_one<unsigned char>(map, pose, max2, step, 1, [](unsigned char v) { return v; });
+    return raycast_one<unsigned char>(g_raycast_map[0], map, pose, max2, step, 1, [](unsigned char v) { return v; });
 }
 template <>
 Pose raycast<double>(const cv::Mat& map, const Pose& pose, double max2, double step)
 {
-    return raycast_one<double>(map, pose, max2, step, 1, [](double v) { return static_cast<uint8_t>(v < 0.5 ? 0 : 255); });
+    return raycast_one<double>(g_raycast_map[1], map, pose, max2, step, 1,
+                               [](double v) { return static_cast<uint8_t>(v < 0.5 ? 0 : 255); });
 }
 template <>
 Pose raycast<int>(const cv::Mat& map, const Pose& pose, double max2, double step)
 {
-    return raycast_one<int>(map, pose, max2, step, 2, [](int v) { return static_cast<uint8_t>(v ? 1 : 0); });
+    return raycast_one<int>(g_raycast_map[2], map, pose, max2, step, 2, [](int v) { return static_cast<uint8_t>(v ? 1 : 0); });
+}
+
+// slam/raycast.cpp:143-223 on the caller's canvas: uploaded, walked and updated on the GPU, read back.
+// (One ray per call, as the reference's signature has it: a caller with many rays for one canvas
+// should hand them to slam_map_raycast_mapping in one call; the filter's own path is MCL::update.)
+Pose raycast_mapping(Particle& particle, double z_squared, double z_max_squared, double step_size)
+{
+    cv::Mat& canvas = particle.map;
+    unsigned char* bytes = &canvas.at<unsigned char>(0, 0);
+    slam_map* m = nullptr;
+    check(slam_map_create(shim_device(), bytes, canvas.rows, canvas.cols, &m), "slam_map_create");
+    const double p3[3] = {particle.pose.x, particle.pose.y, particle.pose.theta};
+    double hit[2] = {-1, -1};
+    int rc = slam_map_raycast_mapping(m, p3, &z_squared, 1, z_max_squared, step_size, hit);
+    if (rc == SLAM_OK) rc = slam_map_download(m, bytes);
+    slam_map_destroy(m);
+    check(rc, "slam_map_raycast_mapping");
+    return {hit[0], hit[1], particle.pose.theta};
+}
+
+double measurement_model_beam(double distance_squared, double stddev, Particle& particle, double max_distance_squared,
+                              double step_size)
+{
+    const Pose hit = raycast_mapping(particle, distance_squared, max_distance_squared, step_size);
+    constexpr double EPSILON = 0.1;
+    if (hit.x == -1)  // no hit
+        return pdf_normal_distribution_clamp(stddev, std::sqrt(distance_squared) - std::sqrt(max_distance_squared)) + EPSILON;
+    const double ddx = hit.x - particle.pose.x, ddy = hit.y - particle.pose.y;
+    const double distance = std::sqrt(ddx * ddx + ddy * ddy);
+    return pdf_normal_distribution_clamp(stddev, distance - std::sqrt(distance_squared)) + EPSILON;
 }
 }  // namespace slam

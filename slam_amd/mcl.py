@@ -277,6 +277,63 @@ class Filter:
         return st
 
 
+class GridMap:
+    """One uint8 grid resident on the GPU (slam_map_* of include/slam_hip.h): FakeLidar scans, batched
+    read-only raycasts (slam/raycast.cpp:7-141, slam/fake_lidar.cpp:15-33) and raycast_mapping on one
+    canvas (slam/raycast.cpp:143-223) without re-uploading the grid per call."""
+
+    def __init__(self, grid_u8, device=0):
+        self.lib = capi.load_library()
+        g = np.ascontiguousarray(grid_u8, dtype=np.uint8)
+        self.rows, self.cols = g.shape
+        self._h = ctypes.c_void_p()
+        check(self.lib.slam_map_create(device, ptr(g), self.rows, self.cols, ctypes.byref(self._h)), self.lib)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.slam_map_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, grid_u8):
+        g = np.ascontiguousarray(grid_u8, dtype=np.uint8)
+        assert g.shape == (self.rows, self.cols)
+        check(self.lib.slam_map_upload(self._h, ptr(g)), self.lib)
+
+    def download(self):
+        g = np.empty((self.rows, self.cols), dtype=np.uint8)
+        check(self.lib.slam_map_download(self._h, ptr(g)), self.lib)
+        return g
+
+    def fake_lidar_scan(self, poses3, start, stop, max_dist, n_rays):
+        """FakeLidar::scan for every pose (x, y, theta): hits (n_poses, n_rays, 2), (-1, -1) = miss; grid 0 = wall."""
+        p = np.ascontiguousarray(poses3, dtype=np.float64).reshape(-1, 3)
+        hits = np.empty((p.shape[0], n_rays, 2))
+        check(self.lib.slam_map_fake_lidar_scan(self._h, ptr(p), p.shape[0], start, stop, max_dist, n_rays, ptr(hits)), self.lib)
+        return hits
+
+    def raycast(self, kind, poses3, max_distance_squared, step_size=0.5):
+        """kind 1: raycast<unsigned char> (hit = cell < 128); kind 2: raycast<int> on a 0/1 grid (hit = 0)."""
+        p = np.ascontiguousarray(poses3, dtype=np.float64).reshape(-1, 3)
+        hits = np.empty((p.shape[0], 2))
+        check(self.lib.slam_map_raycast_batch(self._h, kind, ptr(p), p.shape[0], max_distance_squared, step_size, ptr(hits)), self.lib)
+        return hits
+
+    def raycast_mapping(self, poses3, z_squared, z_max_squared, step_size=1.0):
+        """slam::raycast_mapping for the rays in order on the resident canvas (which is updated): hits (n, 2)."""
+        p = np.ascontiguousarray(poses3, dtype=np.float64).reshape(-1, 3)
+        z2 = np.ascontiguousarray(z_squared, dtype=np.float64).reshape(-1)
+        assert z2.size == p.shape[0]
+        hits = np.empty((p.shape[0], 2))
+        check(self.lib.slam_map_raycast_mapping(self._h, ptr(p), ptr(z2), p.shape[0], z_max_squared, step_size, ptr(hits)), self.lib)
+        return hits
+
+
 @dataclass
 class Particle:  # slam/pose.h:32-37 (map is materialised on request)
     pose: Pose

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "slam/fake_lidar.h"
+#include "slam/raycast.h"
 #include "slam/mcl.h"
 #include "slam/motion.h"
 #include "slam/pose.h"
@@ -76,5 +77,30 @@ int main(int argc, char** argv)
     std::printf("VEL %.17g %.17g %.17g\nPDF %.17g %.17g %.17g\nTRI %d\n", v.x, v.y, v.theta, slam::pdf_normal_distribution(2.0, 0.7),
                 slam::pdf_normal_distribution_clamp(2.0, 9.0), slam::pdf_triangular_distribution(1.5, 0.5),
                 (std::fabs(tri) <= 1.5 * (std::sqrt(6.0) / 2 + 1)) ? 1 : 0);
+    // slam/raycast.h:19-28 on a caller-owned canvas: a fan of rays drawn twice (the second fan meets the first one's walls)
+    {
+        slam::Particle part{{60.5, 40.25, 0.0}, 1.0, cv::Mat(cv::Size(160, 120), CV_8UC1, cv::Scalar(128))};
+        std::printf("RCM");
+        for (int round = 0; round < 2; ++round)
+            for (int k = 0; k < 12; ++k)
+            {
+                part.pose.theta = 0.3 + 0.5 * k;
+                const double z = 20.0 + 3.0 * k;
+                if (k % 3 == 2)
+                {
+                    const double w = slam::measurement_model_beam(z * z, 2.0, part, 70.0 * 70.0);
+                    std::printf(" %.17g", w);
+                }
+                else
+                {
+                    const slam::Pose hit = slam::raycast_mapping(part, k % 4 == 1 ? 70.0 * 70.0 : z * z, 70.0 * 70.0);
+                    std::printf(" %.17g %.17g", hit.x, hit.y);
+                }
+            }
+        unsigned long long hsum = 0;
+        for (int r = 0; r < part.map.rows; ++r)
+            for (int c = 0; c < part.map.cols; ++c) hsum = hsum * 1099511628211ull + part.map.at<unsigned char>(r, c);
+        std::printf("\nRCMMAP %016llx\n", hsum);
+    }
     return 0;
 }

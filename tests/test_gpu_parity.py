@@ -653,6 +653,49 @@ def test_fake_lidar_scan_device(sa):
         assert_bits(out[p], orc.raycast(1, g, poses[p, 0], poses[p, 1], poses[p, 2], 300.0 ** 2, 0.5, math=orc.DET), "raycast")
 
 
+def test_resident_map_handle(sa):
+    """slam_map_*: the grid uploaded once, then scans / raycasts / raycast_mapping on it (slam/fake_lidar.cpp:15-33,
+    slam/raycast.cpp:7-223): the same results as the one-shot entry points and as the oracle."""
+    free = orc.load_map("floor_plan").astype(np.uint8)
+    rng = np.random.default_rng(18)
+    poses = np.stack([rng.uniform(30, 1250, 12), rng.uniform(30, 560, 12), rng.uniform(-3, 3, 12)], 1).copy()
+    gm = sa.GridMap(free)
+    for rep in range(3):  # repeated calls on one handle, growing and shrinking batches
+        n = (12, 3, 7)[rep]
+        hits = gm.fake_lidar_scan(poses[:n], 0.0, 2 * np.pi, 500.0, (90, 360, 17)[rep])
+        for p in range(n):
+            assert_bits(hits[p], orc.fake_lidar_scan(free.astype(np.int32), poses[p], 0.0, 2 * np.pi, 500.0, hits.shape[1], math=orc.DET), "scan")
+    out = gm.raycast(2, poses, 200.0 ** 2, 0.5)
+    for p in range(12):
+        assert_bits(out[p], orc.raycast(2, free.astype(np.int32), poses[p, 0], poses[p, 1], poses[p, 2], 200.0 ** 2, 0.5, math=orc.DET), "raycast<int>")
+    g = (free * 255).astype(np.uint8)
+    gm.upload(g)
+    out = gm.raycast(1, poses, 300.0 ** 2, 0.25)
+    for p in range(12):
+        assert_bits(out[p], orc.raycast(1, g, poses[p, 0], poses[p, 1], poses[p, 2], 300.0 ** 2, 0.25, math=orc.DET), "raycast<uchar>")
+    gm.close()
+    # raycast_mapping on ONE canvas, rays in order (later rays meet earlier rays' walls), two step sizes
+    for step in (1.0, 0.5):
+        canvas = np.full((200, 260), 128, np.uint8)
+        gm = sa.GridMap(canvas)
+        ref = canvas.copy()
+        n = 150
+        rays = np.stack([130 + 5 * rng.standard_normal(n), 100 + 5 * rng.standard_normal(n), rng.uniform(-np.pi, np.pi, n)], 1).copy()
+        rays[:2] = [[-5.0, 100.0, 0.1], [259.5, 199.5, 2.0]]   # from outside the canvas / from its corner
+        z = rng.uniform(0, 90, n)
+        z[::7] = 90.0   # z == zmax: no occupied update (slam/raycast.cpp:205)
+        for rep in range(2):
+            hits = gm.raycast_mapping(rays, z * z, 90.0 ** 2, step)
+            for k in range(n):
+                want, _, _ = orc.raycast_mapping(ref, rays[k, 0], rays[k, 1], rays[k, 2], z[k] * z[k], 90.0 ** 2, step=step, math=orc.DET)
+                assert_bits(hits[k], want, f"hit of ray {k}, repetition {rep}")
+            assert np.array_equal(gm.download(), ref)
+        assert (hits[:, 0] != -1).sum() > 20
+        with pytest.raises(sa.SlamError):
+            gm.raycast_mapping(rays[:1], [91.0 ** 2], 90.0 ** 2)   # the reference asserts z <= zmax (slam/raycast.cpp:145)
+        gm.close()
+
+
 # ---- error behaviour ------------------------------------------------------------------------------------
 def test_errors_are_reported_not_swallowed(sa):
     with pytest.raises(sa.SlamError):

@@ -20,6 +20,36 @@ def test_shim_builds_against_the_c_abi_only():
     assert "hip_runtime" not in src and "slam_hip.h" in src  # host C++ reaches HIP only through the C ABI
 
 
+def test_shim_headers_coexist_with_the_headers_of_a_tree_behind_them():
+    """inside the reference's tree the shim's pose.h / util.h hand over to the tree's own
+    (SLAM_REFERENCE_POSE_H / SLAM_REFERENCE_UTIL_H), so one translation unit can use the planners' types
+    (Coordinate, Box, helpers only the tree's util.h has) together with slam::MCL, and slam_host.cpp leaves
+    the util functions to the tree's util.cpp.  tests/host_cpp/tree_like_reference/ stands for that tree
+    (headers written for this test: the reference's own need OpenCV, absent here)."""
+    root = os.path.join(HERE, "..")
+    tree = os.path.join(HERE, "host_cpp", "tree_like_reference", "slam")
+    flags = ["-std=gnu++17", "-Wall", "-Werror", "-c", "-I", os.path.join(root, "slam_amd", "host", "include", "slam"),
+             "-I", os.path.join(root, "include"), "-I", tree,
+             f'-DSLAM_REFERENCE_POSE_H="{os.path.join(tree, "pose.h")}"', f'-DSLAM_REFERENCE_UTIL_H="{os.path.join(tree, "util.h")}"']
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        for cxx in ("g++", "/opt/rocm/lib/llvm/bin/clang++"):
+            subprocess.run([cxx] + flags + [os.path.join(tree, "..", "tu.cpp"), "-o", os.path.join(d, "tu.o")], check=True)
+            obj = os.path.join(d, "host.o")
+            subprocess.run([cxx] + flags + [os.path.join(root, "slam_amd", "host", "src", "slam_host.cpp"), "-o", obj], check=True)
+            syms = subprocess.run(["nm", "-C", obj], check=True, capture_output=True, text=True).stdout
+            assert " T slam::MCL::update(" in syms and " T slam::raycast_mapping(" in syms and " T slam::measurement_model_beam(" in syms
+            assert " T slam::normalize_angle(" not in syms and " T slam::average_pose(" not in syms  # the tree's util.cpp has them
+        # on its own the shim defines them itself
+        obj = os.path.join(d, "alone.o")
+        subprocess.run(["g++", "-std=gnu++17", "-Wall", "-c", "-I", os.path.join(root, "slam_amd", "host", "include", "slam"),
+                        "-I", os.path.join(root, "include"), os.path.join(root, "slam_amd", "host", "src", "slam_host.cpp"), "-o", obj],
+                       check=True)
+        syms = subprocess.run(["nm", "-C", obj], check=True, capture_output=True, text=True).stdout
+        assert " T slam::normalize_angle(" in syms and " T slam::average_pose(" in syms
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("storage", ["dense", "tiled"])
 def test_cpp_shim_matches_python_path(tmp_path, storage):
@@ -73,6 +103,28 @@ def test_cpp_shim_matches_python_path(tmp_path, storage):
     pdf = [float(t) for t in next(ln for ln in out if ln.startswith("PDF")).split()[1:]]
     assert abs(pdf[0] - 0.18762017345846896) < 1e-15 and pdf[1] == 0.0 and pdf[2] == orc.pdf_triangular(1.5, [0.5])[0]
     assert next(ln for ln in out if ln.startswith("TRI")).split()[1] == "1"
+    # raycast_mapping / measurement_model_beam of the shim (slam/raycast.h:19-28) against the oracle: same call sequence
+    got = [float(t) for t in next(ln for ln in out if ln.startswith("RCM ")).split()[1:]]
+    canvas = np.full((120, 160), 128, np.uint8)
+    want, want_libm = [], []
+    canvas_libm = canvas.copy()
+    for rnd in range(2):
+        for k in range(12):
+            th, z = 0.3 + 0.5 * k, 20.0 + 3.0 * k
+            for cv_, acc, math in ((canvas, want, orc.DET), (canvas_libm, want_libm, orc.LIBM)):
+                if k % 3 == 2:
+                    acc.append(orc.measurement_model_beam(cv_, 60.5, 40.25, th, z * z, 2.0, 70.0 * 70.0, math=math))
+                else:
+                    hit, _, _ = orc.raycast_mapping(cv_, 60.5, 40.25, th, 70.0 * 70.0 if k % 4 == 1 else z * z, 70.0 * 70.0, math=math)
+                    acc.extend(hit.tolist())
+    # hit positions are bit-exact against the oracle's detmath mode; the likelihoods (host libm in the shim) to 1e-12
+    assert len(got) == len(want) and np.allclose(got, want, rtol=1e-12, atol=0)
+    assert np.allclose(got, want_libm, rtol=1e-5)
+    hh = 0
+    for v in canvas.ravel().tolist():
+        hh = (hh * 1099511628211 + v) & 0xFFFFFFFFFFFFFFFF
+    assert int(next(ln for ln in out if ln.startswith("RCMMAP")).split()[1], 16) == hh
+    assert (canvas != 128).sum() > 300 and np.array_equal(canvas, canvas_libm)
 
 
 @pytest.mark.gpu
