@@ -1115,6 +1115,71 @@ def test_full_shard_sizes_of_configs_3_and_5(sa, size, N, B, zmax, uniform):
     f.close()
 
 
+def test_full_shard_size_of_config_4_grid_slam(sa):
+    """One GPU's share of BASELINE configs[3] (full grid_slam loop, 1M particles over 8 GPUs): 125 000 particles
+    with maze-sized 2354 x 2464 canvases as copy-on-write tiles, 90 beams, several filter steps (the app's
+    odometry and alphas, apps/grid_slam.cpp:48-50,132).  Size-independent checks per step: a random subset of
+    particles (poses AND canvases fetched from the big filter) recomputed by the one-thread-per-particle
+    literal kernel on dense canvases gives the same weights, hit cells and canvases bit for bit; a smaller
+    subset by the CPU oracle too; the pool never runs dry; the selection stays in range and the gathered
+    state is the selected state."""
+    import time
+
+    N, B, rows, cols = 125_000, 90, 2354, 2464
+    free = orc.load_map("maze")
+    assert free.shape == (rows, cols)
+    rng = np.random.default_rng(4)
+    odom, alphas = [0.0, 2.5, 0.0], [1e-3] * 4
+    true = [1944.5, 2188.5, np.pi / 2]  # a place of the maze with 40 cells of clearance and a mean range of ~140 cells
+    gm = sa.GridMap(free.astype(np.uint8))
+    pool = 16_000_000  # 64 GB: every particle copies the ~40 tiles its scan writes in every pass (clones share tiles again after each resample)
+    f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=0x5EED4004, sort=sa.capi.SORT_NONE, map_storage=sa.capi.MAPS_TILED,
+                  tile_pool_tiles=pool)
+    S, SO = 48, 3
+    small = sa.Filter(S, rows, cols, mode=sa.capi.MODE_SLAM, sort=sa.capi.SORT_NONE, map_storage=sa.capi.MAPS_DENSE,
+                      raycaster=sa.capi.RAYCAST_FAST_PARTICLE_LANES)
+    small.record_hits(True)
+    for step in range(4):
+        true = [true[0] + 2.5 * np.cos(true[2]), true[1] + 2.5 * np.sin(true[2]), true[2]]
+        sensor = orc.sensor_position(true, OFFSET, orc.DET)
+        ang, dist = orc.hits_to_scan(gm.fake_lidar_scan(sensor, 0.0, 2 * np.pi, 500.0, B)[0], sensor, 0.0, 2 * np.pi, 500.0)
+        f.predict(odom, alphas)
+        x, y, th = f.poses()
+        sub = np.sort(rng.choice(N, S, replace=False))
+        before = np.stack([f.map_of(int(p)) for p in sub])
+        t0 = time.perf_counter()
+        f.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+        dt = time.perf_counter() - t0
+        w = f.weights()
+        st, ts = f.stats(), f.tile_stats()
+        print(f"\nstep {step}: weighting pass of {N} x {B} on {rows}x{cols} tiles {dt * 1e3:.1f} ms; per ray {st['cells_read'] / (N * B):.1f} cells read, "
+              f"{st['cells_written'] / (N * B):.1f} written; tiles live {ts['live']} + copied {ts['allocated_since']} of {ts['pool']}")
+        assert ts["live"] + ts["allocated_since"] < pool
+        small.set_poses(x[sub], y[sub], th[sub])
+        small.set_maps(before)
+        small.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+        assert_bits(w[sub], small.weights(), f"step {step}: subset recomputed by the literal kernel on dense canvases")
+        for k, p in enumerate(sub):
+            assert np.array_equal(f.map_of(int(p)), small.map_of(k)), f"step {step}: canvas of particle {p}"
+        ow, oxy, ocell, _ = orc.update_weights(x[sub[:SO]], y[sub[:SO]], th[sub[:SO]], before[:SO].copy(), ang, dist, 5.0, 500.0, OFFSET,
+                                               slam_mode=True, want_hits=True, math=orc.DET)
+        assert_bits(w[sub[:SO]], ow, f"step {step}: subset vs oracle")
+        assert np.array_equal(small.hits()[1][:SO], ocell)
+        if step:
+            assert (ocell >= 0).any()  # from the second scan on the rays meet the walls the first one drew
+        f.resample()
+        idx = f.last_indices()
+        assert idx.min() >= 0 and idx.max() < N
+        nx, ny, nth = f.poses()
+        assert_bits(nx, x[idx], "gathered x"), assert_bits(ny, y[idx], "gathered y"), assert_bits(nth, th[idx], "gathered theta")
+        assert_bits(f.weights(), w[idx], "gathered weights")
+        k = int(rng.integers(0, S))
+        hit = np.flatnonzero(idx == sub[k])
+        if hit.size:  # a selected particle carries its source's canvas (slam/mcl.cpp:147-155)
+            assert np.array_equal(f.map_of(int(hit[0])), small.map_of(k))
+    small.close(), f.close(), gm.close()
+
+
 # ---- BASELINE configs[2] and [4] at reduced particle counts: synthetic grids, long ranges, seeding ----
 def test_seeding_matches_host_replay(sa):
     from slam_amd import synth
