@@ -112,6 +112,195 @@ def cpu_baseline(free, ang, dist, n_beams, budget_s=12.0):
                       f"reference's slicing"}
 
 
+def source_fingerprint():
+    """Hash of the kernel sources: a recorded counter value is only quoted while the code it was taken from is unchanged."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "slam_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def slam_scans(sa, free, device, n_beams, true0, n_steps):
+    """apps/grid_slam.cpp:144-166: one scan per robot pose while the robot drives straight on (UP key: 2.5 per frame)."""
+    poses, (x, y, th) = [], true0
+    for _ in range(n_steps):
+        x, y = x + 2.5 * np.cos(th), y + 2.5 * np.sin(th)
+        poses.append((x, y, th))
+    return synth_scans(sa, free, device, n_beams, poses)
+
+
+def slam_cpu_baseline(scans, rows, cols, n_beams, n=None):
+    """CPU oracle in SLAM mode (walk + occupancy update, threaded like slam/mcl.cpp:120-137; resample with the deep
+    copy of slam/mcl.cpp:147-155) on a bounded number of particles: the time of its last step."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc
+
+    cores = min(16, len(os.sched_getaffinity(0)))
+    n = n or max(cores, min(256, int(3.0e8 // (rows * cols))))  # canvases of the sample within ~300 MB
+    maps = np.full((n, rows, cols), 128, np.uint8)
+    xs, ys, ths = np.full(n, cols / 2.0), np.full(n, rows / 2.0), np.full(n, np.pi / 2)
+    odom, alphas = [0.0, 2.5, 0.0], [1e-3] * 4
+    steps = min(5, len(scans))
+    for k in range(steps):
+        xs, ys, ths = orc.predict(xs, ys, ths, odom, alphas, orc.philox_normals(1, k, 0, n))
+        t0 = time.perf_counter()
+        w, _ = orc.update_weights(xs, ys, ths, maps, *scans[k], STDDEV, MAX_DIST, OFFSET, slam_mode=True, n_threads=cores, fast=True)
+        idx, _, _ = orc.resample(w, orc.philox_uniforms(1, k, 0, n))
+        src = idx[orc.sort_order(w[idx], 1)]
+        maps = maps[src]
+        xs, ys, ths = xs[src], ys[src], ths[src]
+        dt = time.perf_counter() - t0
+    return {"value": n * n_beams / dt, "unit": "particle-beams/s", "cores": cores, "kind": "port",
+            "sample": f"{n} particles x {n_beams} beams with {rows}x{cols} canvases, step {steps} of the same scans "
+                      f"(update + resample with deep copy), {dt:.2f} s, oracle built -Ofast, {cores} threads"}
+
+
+def slam_entry(sa, capi, device, label, n, rows, cols, free, true0, pool, steps, warmup, with_cpu):
+    """Grid-SLAM mode (exactly slam::MCL: per-particle canvases updated along every ray), 90 beams, the app's
+    sensor (apps/grid_slam.cpp:88-99) and motion noise (:132); canvases as copy-on-write tiles."""
+    import torch
+
+    B = 90
+    extra = 3
+    scans = slam_scans(sa, free, device, B, true0, warmup + steps + extra)
+    f = sa.Filter(n, rows, cols, mode=capi.MODE_SLAM, device=device, seed=SEED, map_storage=capi.MAPS_TILED, tile_pool_tiles=pool,
+                  async_launch=True)
+    odom, alphas = [0.0, 2.5, 0.0], [1e-3] * 4
+    k = 0
+    for _ in range(warmup):
+        f.predict(odom, alphas); f.update(*scans[k], STDDEV, MAX_DIST, OFFSET); k += 1
+    f.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        f.predict(odom, alphas); f.update(*scans[k], STDDEV, MAX_DIST, OFFSET); k += 1
+    f.synchronize()
+    ms_step = (time.perf_counter() - t0) / steps * 1e3
+    # roofline of the walk kernel from the next steps, one at a time (the counters of a pass are read after it)
+    f.profile(True)
+    f.kernel_ms()
+    alg = 0.0
+    reads = writes = 0.0
+    for _ in range(extra):
+        f.predict(odom, alphas); f.update_weights(*scans[k], STDDEV, MAX_DIST, OFFSET); k += 1
+        st = f.stats()
+        reads += st["cells_read"]; writes += st["cells_written"]
+        alg += st["cells_read"] + st["cells_written"] + 40.0 * n + 16.0 * B   # SURVEY.md §8d, S mode
+        f.resample()
+    f.synchronize()
+    kms = f.kernel_ms()
+    f.profile(False)
+    tiles = f.tile_stats()
+    f.close()
+    torch.cuda.synchronize()
+    w_ms = kms["weights"][0] / max(kms["weights"][1], 1)
+    achieved = alg / extra / (w_ms * 1e-3) / 1e9
+    out = {
+        "workload": label, "value": n * B / (ms_step * 1e-3), "unit": "particle-beams/s", "ms_per_step": ms_step, "steps": steps,
+        "warmup": warmup, "dtype": "f64 positions / u8 cells",
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_weights_S2<tiled> (walk + occupancy update + beam likelihood)", "kernel_avg_ms": w_ms,
+                     "algorithmic_bytes_per_launch": alg / extra, "cells_read_per_ray": reads / extra / (n * B),
+                     "cells_written_per_ray": writes / extra / (n * B),
+                     "note": "bytes = cells read + cells written (counted by the kernel) + 40 B per particle; the kernel is "
+                             "instruction-issue bound (DESIGN.md), this fraction is reported, not claimed"},
+        "kernel_ms_per_step": {g: v[0] / max(extra, 1) for g, v in kms.items()},
+        "tiles": tiles,
+    }
+    if with_cpu:
+        out["cpu_baseline"] = slam_cpu_baseline(scans, rows, cols, B)
+    return out
+
+
+def localization_shard_entry(sa, capi, device, label, size, n, B, zmax, uniform, steps):
+    """One GPU's share of BASELINE configs[2] / configs[4]: localization on the synthetic grids of slam_amd/synth.py,
+    log-domain weights (the linear ones underflow beyond ~434 beams), sigma 0.5."""
+    import torch
+
+    from slam_amd import synth
+
+    g = synth.make_grid(size)
+    free01 = (g >= 128).astype(np.uint8)
+    free_cells = np.argwhere(g[size // 4:size // 4 + 64, size // 4:size // 4 + 2000] >= 128)
+    ci, cj = free_cells[len(free_cells) // 2]
+    true = [float(cj + size // 4) + 0.5, float(size - 1 - (ci + size // 4)) + 0.5, 0.7]
+    sensor = sa.MCL.sensor_position(sa.Pose(*true), sa.Pose(*OFFSET))
+    gm = sa.GridMap(free01, device=device)
+    hits = gm.fake_lidar_scan([sensor.x, sensor.y, sensor.theta], 0.0, 2 * np.pi, zmax, B)[0]
+    gm.close()
+    ang = np.arange(B) * (2 * np.pi / B) - np.pi
+    dist = np.where(hits[:, 0] != -1, np.hypot(hits[:, 1] - sensor.y, hits[:, 0] - sensor.x), zmax)
+    f = sa.Filter(n, size, size, device=device, seed=SEED, sort=capi.SORT_NONE, weight_domain=capi.WEIGHT_LOG, async_launch=True)
+    f.set_map(g)
+    if uniform:
+        f.seed_uniform_free()
+    else:
+        f.seed_gaussian(true, [25.0, 25.0, 0.2])
+    # one weighting pass per step on the seeded cloud (a resample would collapse the uniform cloud: the regime
+    # on record here is the wide one); the cells of the reference's walk from a subset on the cell-by-cell kernel
+    f.predict(ODOM, ALPHAS)
+    f.update_weights(ang, dist, 0.5, zmax, OFFSET)
+    f.synchronize()
+    f.profile(True)
+    f.kernel_ms()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        f.predict(ODOM, ALPHAS)
+        f.update_weights(ang, dist, 0.5, zmax, OFFSET)
+    f.synchronize()
+    ms_step = (time.perf_counter() - t0) / steps * 1e3
+    kms = f.kernel_ms()
+    x, y, th = f.poses()
+    f.close()
+    sub = np.random.default_rng(0).choice(n, 4096, replace=False)
+    wk = sa.Filter(4096, size, size, device=device, raycaster=capi.RAYCAST_WALK, sort=capi.SORT_NONE, weight_domain=capi.WEIGHT_LOG)
+    wk.set_map(g)
+    wk.set_poses(x[sub], y[sub], th[sub])
+    wk.update_weights(ang, dist, 0.5, zmax, OFFSET)
+    sbar = wk.stats()["cells_read"] / (4096.0 * B)
+    wk.close()
+    torch.cuda.synchronize()
+    w_ms = kms["weights"][0] / max(kms["weights"][1], 1)
+    alg = n * B * sbar + 40.0 * n + 16.0 * B
+    achieved = alg / (w_ms * 1e-3) / 1e9
+    return {
+        "workload": label, "value": n * B / (ms_step * 1e-3), "unit": "particle-beams/s", "ms_per_step": ms_step, "steps": steps,
+        "dtype": "f64", "step": "predict + weighting pass (no resample: the seeded cloud stays wide)",
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "weighting pass (k_order_keys + sort + k_rays_pl [+ k_sum_lw])", "kernel_avg_ms": w_ms,
+                     "algorithmic_bytes_per_launch": alg, "cells_per_ray_reference_walk": sbar,
+                     "note": "algorithmic, reference-equivalent bytes (cells the reference's walk reads, from 4096 particles on the "
+                             "cell-by-cell kernel); the clearance search reads far fewer"},
+    }
+
+
+def secondary_entries(sa, capi, device, with_cpu):
+    """Configurations next to the headline one (BASELINE configs[0], [3], [2], [4] at one GPU's share)."""
+    out = []
+    want = os.environ.get("BENCH_SECONDARY", "slam1k,slam125k,loc8192,loc16384").split(",")
+    if "slam1k" in want:
+        out.append(slam_entry(sa, capi, device,
+                              "BASELINE configs[0] shape on the GPU: grid-SLAM (slam::MCL), assets/map.png scans, 1000 particles x 90 beams, "
+                              "1000x1000 canvases (tiled), full step = predict + update (walk + map update, select, sort, clone)",
+                              1000, 1000, 1000, load_free_grid("map"), (400.0, 400.0, np.pi / 90), 0, 20, 5, with_cpu))
+    if "slam125k" in want:
+        out.append(slam_entry(sa, capi, device,
+                              "BASELINE configs[3], one GPU's share of 8: grid-SLAM, assets/maze.png scans (robot at (1944.5, 2188.5), mean range "
+                              "~140 cells), 125000 particles x 90 beams, 2354x2464 canvases as copy-on-write tiles (64 GB pool)",
+                              125_000, 2354, 2464, load_free_grid("maze"), (1944.5, 2188.5, np.pi / 2), 16_000_000, 8, 3, False))
+    if "loc8192" in want:
+        out.append(localization_shard_entry(sa, capi, device, "BASELINE configs[2], one GPU's share of 8: 1.25M particles x 1080 beams, synthetic "
+                                            "8192^2 grid, Gaussian cloud, max_dist 500, sigma 0.5, log-domain weights", 8192, 1_250_000, 1080,
+                                            500.0, False, 3))
+    if "loc16384" in want:
+        out.append(localization_shard_entry(sa, capi, device, "BASELINE configs[4], one GPU's share of 8: 12.5M uniformly seeded particles x 720 "
+                                            "long-range beams (max_dist 4000), synthetic 16384^2 grid, sigma 0.5, log-domain weights",
+                                            16384, 12_500_000, 720, 4000.0, True, 2))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +309,7 @@ def main():
     ap.add_argument("--particles", type=int, default=100_000, help="particles per GPU")
     ap.add_argument("--beams", type=int, default=360)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline configuration only")
     args = ap.parse_args()
 
     import torch
@@ -222,10 +412,14 @@ def main():
         alg_bytes = n_loc * B * sbar + 40.0 * n_loc + 16.0 * B
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
         traffic = None
+        # HBM bytes per launch from the rocprofv3 PMC passes of profiles/run_profile.sh: quoted only while the
+        # kernel sources are the ones the counters were taken from (the file records their fingerprint)
         pmc = os.path.join(ROOT, "profiles", "pmc_weights_kernel.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                if rec.get("source_fingerprint") == source_fingerprint():
+                    traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -251,6 +445,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "note": "achieved/frac are ALGORITHMIC, reference-equivalent bytes (cells the reference's walk would read, SURVEY.md §8d) "
+                        "over the kernel time; the clearance search reads far fewer bytes and the binding limit is VALU issue (DESIGN.md §6)",
                 "kernel": "weighting pass = k_order_keys + radix sort + k_rays_pl + k_sum_lw (raycast + beam likelihood)", "kernel_avg_ms": k_avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes, "cells_per_ray_reference_walk": sbar,
                 "kernel_particle_beams_per_s": n_loc * B / (k_avg_ms * 1e-3),
@@ -260,6 +456,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(free, ang, dscan, B)
+        if world == 1 and not sharded and not args.no_secondary:
+            f.close()
+            out["secondary"] = secondary_entries(sa, capi, local_rank, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

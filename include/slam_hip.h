@@ -158,7 +158,9 @@ int slam_mcl_average_pose(slam_mcl* h, double out[3]);
 /* Counters of the last update_weights: {cells read, cells written, steps}; SLAM_RAYCAST_WALK and SLAM mode only. */
 int slam_mcl_get_stats(slam_mcl* h, int64_t out[3]);
 /* Accumulated device time (HIP events on the handle's stream) per kernel group since the last
- * reset: out[0] predict, [1] weights, [2] resample (scan+select+gather), [3] sort, [4] map clone;
+ * reset: out[0] predict, [1] weights (the ray kernels), [2] resample (scan+select+gather), [3] sort, [4] map clone
+ * (dense: the deep copy after the selection; tiles: table gather + census, and the copy-on-write copies made just
+ * before the next weighting pass);
  * launches[k] = number of launches accumulated.  Enable with slam_mcl_profile(h, 1). */
 int slam_mcl_profile(slam_mcl* h, int32_t enable);
 int slam_mcl_get_kernel_ms(slam_mcl* h, double ms[5], int64_t launches[5], int32_t reset);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <rocprim/rocprim.hpp>
@@ -390,7 +391,10 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                                                (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096));
     if (!(particle_lanes && order_mode > 0 && h->n >= 3))  // k_order_keys zeroes the counters itself
         HIPCHK(hipMemsetAsync(h->stats, 0, 3 * sizeof(unsigned long long), h->stream));
-    slam_mcl::Span span(h, G_WEIGHTS);
+    // device time of the weighting kernels proper; tiled canvases first make their deferred copies
+    // (the map clone of slam/mcl.cpp:147-155, accounted to that group)
+    std::unique_ptr<slam_mcl::Span> wspan;
+    if (!(slam_mode && h->tiled)) wspan.reset(new slam_mcl::Span(h, G_WEIGHTS));
     if (slam_mode)
     {
         a.grid = h->maps;
@@ -413,6 +417,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         if (h->tiled)
         {
             // make every tile within sensor range exclusive up front (parallel), then walk
+            std::unique_ptr<slam_mcl::Span> copies(new slam_mcl::Span(h, G_CLONE));
             const double range = a.zmax + 3.0;
             // (bounding square in tiles; capped: what it misses is copied inside the kernel)
             const int span = 2 * std::max(h->tile_T / h->tile_tc, h->tile_tc) + 1;
@@ -443,6 +448,8 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             hipLaunchKernelGGL(slamk::k_tile_plan, dim3((unsigned)cdiv(h->n, 16 * slamk::TILE_PLAN_PW)), dim3(1024), 0, h->stream, h->n, h->x, h->y, h->th, a.sd,
                                a.stheta, a.srot, range, h->tile_sector, h->rows, h->cols, side, ta, pl);
             hipLaunchKernelGGL(slamk::k_tile_copy, dim3((unsigned)blocks), dim3(256), 0, h->stream, ta, pl);
+            copies.reset();
+            wspan.reset(new slam_mcl::Span(h, G_WEIGHTS));
             size_t lds = 0;
             if ((size_t)h->tile_T * 16 <= 48 * 1024)
             {

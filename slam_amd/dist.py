@@ -93,8 +93,9 @@ class HipShard:
 class ShardedFilter:
     """The filter step over `world` ranks.  `backend` is the local shard (HipShard in production)."""
 
-    def __init__(self, backend, world=None, group=None, always_collective=False, split_exchange=False):
+    def __init__(self, backend, world=None, group=None, always_collective=False, split_exchange=False, stage_exchange=False):
         self.b = backend
+        self.stage_exchange = stage_exchange
         self.group = group
         self.always_collective = always_collective  # issue the all-gather even for one rank (rehearsal)
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
@@ -121,35 +122,34 @@ class ShardedFilter:
             if local.is_cuda:
                 self._comm = torch.cuda.Stream(device=local.device)
         if self._comm is None:
-            self._stage_p.copy_(local[:n3])
-            dist.all_gather_into_tensor(self._gp, self._stage_p, group=self.group)
+            dist.all_gather_into_tensor(self._gp, local[:n3], group=self.group)
             return
         # the side stream waits for predict (and, through it, for the previous resample, the last
         # reader of _gp); the resample of this step waits for _poses_done
         self._comm.wait_event(torch.cuda.current_stream(local.device).record_event())
         with torch.cuda.stream(self._comm):
-            self._stage_p.copy_(local[:n3])
-            dist.all_gather_into_tensor(self._gp, self._stage_p, group=self.group)
+            dist.all_gather_into_tensor(self._gp, local[:n3], group=self.group)
             self._poses_done = self._comm.record_event()
 
     def update(self, angles, dists, stddev, max_dist, offset=(0.0, 0.0, 0.0)):
         self.b.update_weights(angles, dists, stddev, max_dist, offset)
         local = self.b.packed_state()
         if self._split:
-            self._stage_w.copy_(local[self._stage_p.numel():])
-            dist.all_gather_into_tensor(self._gw, self._stage_w, group=self.group)
+            dist.all_gather_into_tensor(self._gw, local[self._stage_p.numel():], group=self.group)
             if self._poses_done is not None:
                 torch.cuda.current_stream(local.device).wait_event(self._poses_done)
             self.b.shard_resample_split(self._gp, self._gw, self.world)
             return
         if self.world > 1 or self.always_collective:
-            # the one exchange step of the path: all-gather of [x | y | theta | w] of every shard.
-            # The library's buffer is viewed zero-copy; it is staged through a torch-allocated
-            # tensor (32 B/particle) so that RCCL only ever sees allocator-owned memory.
-            if self._stage is None:
-                self._stage = torch.empty_like(local)
-            self._stage.copy_(local)
-            dist.all_gather_into_tensor(self._gathered, self._stage, group=self.group)
+            # the one exchange step of the path: all-gather of [x | y | theta | w] of every shard, straight
+            # out of the library's resident buffer (a zero-copy view: RCCL reads plain device memory, no
+            # staging copy; `stage_exchange` keeps the old detour through a torch-allocated tensor)
+            if self.stage_exchange:
+                if self._stage is None:
+                    self._stage = torch.empty_like(local)
+                self._stage.copy_(local)
+                local = self._stage
+            dist.all_gather_into_tensor(self._gathered, local, group=self.group)
         else:
             self._gathered.copy_(local)
         if not getattr(self.b, "slam_mode", False):
