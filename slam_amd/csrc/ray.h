@@ -265,7 +265,11 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, int pitch, int rows, int cols, double 
     const double rows_d = (double)rows;
     // accumulated rounding stays far below the distance margin only for moderate coordinates;
     // anything farther out starts (and stays) outside every supported grid: literal loop only.
-    int left = (dm_fabs(sx) < 1048576.0 && dm_fabs(sy) < 1048576.0) ? k_safe : 0;
+    // (the literal loop then runs the whole range instead of only its last samples: a ray that starts just
+    // outside a 2^20-cell side and heads inward is walked as far as the reference walks it)
+    const bool far_out = !(dm_fabs(sx) < 1048576.0 && dm_fabs(sy) < 1048576.0);
+    int left = far_out ? 0 : k_safe;
+    const int tail = far_out ? k_safe + 16 : 16;
     double x = sx, y = sy;
     // sample 0 (the start cell) is never tested (slam/raycast.cpp:153-157); its clearance still
     // tells how far the first jump may go.
@@ -381,7 +385,7 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, int pitch, int rows, int cols, double 
     // the literal loop from sample k_safe on (dedupe against the previous sample's cell, bounds,
     // hit, distance limit)
     int pi = i, pj = j;
-    for (int it = 0; it < 16; ++it)
+    for (int it = 0; it < tail; ++it)
     {
         x += dx;
         y += dy;

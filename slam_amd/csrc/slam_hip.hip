@@ -974,8 +974,11 @@ SLAM_API int slam_mcl_set_weights(slam_mcl* h, const double* w, int64_t first, i
     int rc = check_handle(h);
     if (rc) return rc;
     if (!w || first < 0 || count < 0 || first + count > h->n) return fail(SLAM_ERR_ARG, "set_weights: bad range");
+    // linear weights are likelihoods (>= 0); a SLAM_WEIGHT_LOG handle holds sums of logs in that column (any finite value)
+    const bool log_domain = h->prm.weight_domain == SLAM_WEIGHT_LOG;
     for (int64_t k = 0; k < count; ++k)
-        if (!(w[k] >= 0) || !std::isfinite(w[k])) return fail(SLAM_ERR_ARG, "set_weights: weights must be finite and >= 0");
+        if (!std::isfinite(w[k]) || (!log_domain && !(w[k] >= 0)))
+            return fail(SLAM_ERR_ARG, log_domain ? "set_weights: log-domain weights must be finite" : "set_weights: weights must be finite and >= 0");
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->w + first, w, sizeof(double) * count, hipMemcpyHostToDevice));
     return SLAM_OK;

@@ -696,6 +696,29 @@ def test_resident_map_handle(sa):
         gm.close()
 
 
+def test_log_domain_weights_can_be_set_and_restored(sa):
+    """A SLAM_WEIGHT_LOG handle holds sums of logs (<= 0) in its weight column: set_weights takes them back, and the
+    selection then runs on exp(lw - max lw) as after a weighting pass; a linear handle still refuses negatives."""
+    N = 3000
+    rng = np.random.default_rng(5)
+    lw = -rng.uniform(0, 900, N)   # far beyond what exp() can represent in the linear domain
+    u = orc.reference_uniforms(N, 11)
+    f = sa.Filter(N, 16, 16, noise=sa.capi.NOISE_INJECTED, sort=sa.capi.SORT_NONE, weight_domain=sa.capi.WEIGHT_LOG)
+    f.set_weights(lw)
+    assert_bits(f.weights(), lw, "log weights read back")
+    f.set_noise(canonical_uniforms=u)
+    f.resample()
+    want, _, _ = orc.resample(orc.log_domain_weights(lw, math=orc.DET), u, orc.ORDER_BLOCKED)
+    assert np.array_equal(f.last_indices(), want)
+    with pytest.raises(sa.SlamError):
+        f.set_weights(np.array([np.nan]))
+    f.close()
+    lin = sa.Filter(8, 16, 16)
+    with pytest.raises(sa.SlamError):
+        lin.set_weights(-np.ones(8))
+    lin.close()
+
+
 # ---- error behaviour ------------------------------------------------------------------------------------
 def test_errors_are_reported_not_swallowed(sa):
     with pytest.raises(sa.SlamError):

@@ -109,6 +109,21 @@ def test_fast_hit_search_equals_literal_walk(hh, name):
     assert compare(hh, g, sx, sy, th, 500.0)[0] == 0
 
 
+def test_rays_from_beyond_two_to_the_twenty_are_walked_to_the_end(hh):
+    """A grid side of 2^20 cells (the largest create() accepts): a ray that starts just outside it and heads inward
+    lies in the coordinate range that takes the literal loop only; it must be walked as far as the reference walks
+    it (slam/raycast.cpp:163-220 has no sample limit), not cut after a few samples."""
+    rows, cols = 6, 1 << 20
+    g = np.full((rows, cols), 255, np.uint8)
+    g[:, cols - 300] = 0   # a wall 300 cells inside
+    sx = np.array([cols + 0.5, cols + 0.25, cols + 0.5, cols - 0.5])
+    sy = np.array([2.5, 3.5, 2.5, 1.5])
+    th = np.array([np.pi, np.pi, 0.0, np.pi])
+    bad, first, _, _, hits, _ = compare(hh, g, sx, sy, th, 500.0)
+    assert bad == 0, first
+    assert abs(hits[0, 0] - (cols - 299.5)) < 1.0 and hits[2, 0] == -1.0 and hits[3, 0] > 0
+
+
 def test_fast_hit_search_matches_the_oracle_walk(hh):
     """The harness' literal walk is the same source as the kernels'; tie it to the oracle as well."""
     rng = np.random.default_rng(3)
