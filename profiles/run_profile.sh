@@ -3,14 +3,16 @@
 #   kernel-trace + stats, then PMC passes in runs of their own (never combined with tracing).
 # Usage: bash profiles/run_profile.sh <tag>      -> gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+# counter passes: the headline configuration plus the 125 000-particle grid-SLAM shard (k_weights_S2)
+export BENCH_SECONDARY=${BENCH_SECONDARY_PMC:-slam125k}
 BENCH="python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
 # the trace pass runs bench.py with its defaults (5 warm-up + 20 timed steps): the same command the bench line comes from
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- python3 $REPO/bench.py --no-cpu-baseline > "$OUT/trace.log" 2>&1 || exit 1
+BENCH_SECONDARY=slam1k,slam125k,loc8192,loc16384 timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- python3 $REPO/bench.py --no-cpu-baseline > "$OUT/trace.log" 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o bench -- $BENCH > "$OUT/pmc_fetch.log" 2>&1 || exit 2
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" -o bench -- $BENCH > "$OUT/pmc_l2.log" 2>&1 || exit 3
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD -d "$OUT/pmc_sq" -o bench -- $BENCH > "$OUT/pmc_sq.log" 2>&1 || exit 4
