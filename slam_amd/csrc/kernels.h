@@ -117,8 +117,8 @@ struct WeightArgs
 {
     int64_t n;
     const double *x, *y, *th;
-    uint8_t* grid;         // L/FAST: clearance grid; L/WALK: raw map; S: per-particle maps
-    size_t map_stride;     // S mode: bytes between particle maps
+    uint8_t* grid;         // L/FAST: the 8 cone-clearance planes; L/WALK: raw map; S: per-particle maps
+    size_t map_stride;     // S mode: bytes between particle maps; L/FAST: bytes between clearance planes
     int rows, cols, B;
     const double *angles, *z2, *z;  // per beam: angle, dist^2, sqrt(dist^2)
     double zmax2, zmax, stddev, norm, log_eps;
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
             dm_sincos(theta, &s, &c);
             slam_ray_result r;
             if (VARIANT == 0)
-                ray_fast_L(a.grid, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr);
+                ray_fast_L(a.grid, a.map_stride, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr);
             else
                 ray_walk<false, true>(a.grid, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, nullptr, nullptr,
                                       a.max_iter, &r, &st);
@@ -217,9 +217,10 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     dm_sincos(pth + a.stheta, &s0, &c0);
     const double sx = px + c0 * a.sd;
     const double sy = py + s0 * a.sd;
-    int i0, j0;
-    unsigned e0;
-    slam_ray_origin(a.grid, a.cols + 4, a.rows, a.cols, sx, sy, &i0, &j0, &e0, nullptr);
+    // start cell (the same for every beam of the particle); its clearance is read per beam from the plane of the beam's octant
+    const int i0 = slam_f2i(((double)a.rows - sy) - 1.0), j0 = slam_f2i(sx);
+    const bool inb0 = slam_in_bounds(a.rows, a.cols, i0, j0);
+    const unsigned off0 = inb0 ? (unsigned)(slam_mul24(i0, a.cols + 4) + j0 + 2 * (a.cols + 4) + 2) : 0u;  // (frame corner: 0)
     double* slab = a.lw + (size_t)pb * (size_t)a.B * 64 + lane;
     const int b0 = seg * a.seg_beams;
     const int b1 = (b0 + a.seg_beams) < a.B ? (b0 + a.seg_beams) : a.B;
@@ -229,7 +230,8 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
         double s, c;
         dm_sincos(theta, &s, &c);
         slam_ray_result r;
-        ray_fast_L0(a.grid, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, i0, j0, e0, &r, nullptr);
+        const uint8_t* plane = a.grid + (size_t)slam_octant(c, s) * a.map_stride;
+        ray_fast_L0(plane, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, i0, j0, plane[off0], &r, nullptr);
         slab[(size_t)b * 64] = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
         if (a.hit_xy)
         {

@@ -15,13 +15,13 @@
 // margin).  The add that crosses a binade edge, the few adds inside the margin before it, ties and
 // |x| < 4 use real adds.
 //
-// (b) Clearance grid E (uint8 per cell, built by the library when the map is set, stored with a
-// two-cell frame of zeros, see clearance.h): E = 0 for an
-// occupied cell (< 128), otherwise min(255, Chebyshev distance to the nearest occupied or
-// out-of-grid cell) >= 1.  From a sample inside a cell with E >= 1, all cells within Chebyshev
-// distance E-1 are free and in bounds, and a step moves at most max(|dx|,|dy|) per axis, so the
-// next floor((E-1)/max(|dx|,|dy|)) samples can neither hit nor leave the grid and need no read.
-// Distance-limit tests are only needed near k = zmax and are done by the literal loop (the tail).
+// (b) Clearance.  Per cell and per octant of the ray's direction a uint8 C (clearance.h, built by the
+// library when the map is set, stored with a two-cell frame of zeros): C = 0 for an occupied cell
+// (< 128), otherwise >= 1 and such that every cell the ray can visit within its next
+// floor((C-1)/max(|dx|,|dy|)) samples is free and in bounds, so those samples need no read.  (Round 1
+// used one Chebyshev distance for all directions; a plane per octant only looks ahead, which about
+// halves the reads.)  Distance-limit tests are only needed near k = zmax and are done by the literal
+// loop (the tail).
 #pragma once
 #include <stdint.h>
 
@@ -230,16 +230,17 @@ DM_HD void slam_advance(slam_axis* X, slam_axis* Y, double dx, double dy, int m)
 // Localization-mode hit search: identical result to ray_walk<false> on the uint8 map the
 // clearance grid was built from.
 //
-// Ep is the PADDED clearance grid: (rows+4) x pitch bytes, pitch = cols+4, cell (i,j) at
-// Ep[(i+2)*pitch + (j+2)], the two-cell frame filled with 0.  A jump chosen from clearance e lands
-// at most e cells (Chebyshev) from an in-bounds cell whose nearest outside cell is >= e away, so a
-// landing sample is either in bounds or in the first ring outside; the frame lets the hot loop read
-// it without a bounds test, and "e == 0" means "hit or left the grid" (told apart afterwards).
+// Ep is the PADDED clearance plane of the ray's octant: (rows+4) x pitch bytes, pitch = cols+4, cell
+// (i,j) at Ep[(i+2)*pitch + (j+2)], the two-cell frame filled with 0 (and counted as occupied when the
+// planes are built).  A jump chosen from clearance C lands in the cone's column a <= C, and the cone
+// (two cells wider than the ray can get) meets the frame before the ray does, so a landing sample is
+// either in bounds or in the first ring outside; the frame lets the hot loop read it without a bounds
+// test, and "0" means "hit or left the grid" (told apart afterwards).
 // k_safe = max(0, floor(zmax) - 1): for samples k <= k_safe the distance test of
 // slam/raycast.cpp:216 cannot fire (k^2 <= zmax^2 - 2 zmax + 1).
 //
-// The start cell of a ray and its clearance (0 when the origin is outside the grid): the same for
-// every beam of a particle, so the kernels look it up once per particle.
+// The start cell of a ray (the same for every beam of a particle) and its clearance in the plane of the
+// ray's octant (0 when the origin is outside the grid).
 DM_HD void slam_ray_origin(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, int* i0, int* j0,
                            unsigned* e0, unsigned* reads)
 {
@@ -408,9 +409,17 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, int pitch, int rows, int cols, double 
     }
 }
 
-DM_HD void ray_fast_L(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
-                      double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
+// Octant of a direction, the index of the cone-clearance plane its ray reads (clearance.h).
+DM_HD int slam_octant(double dx, double dy)
 {
+    return (dx < 0.0 ? 1 : 0) | (dy < 0.0 ? 2 : 0) | (dm_fabs(dx) < dm_fabs(dy) ? 4 : 0);
+}
+
+// planes: the 8 cone-clearance planes, plane_stride bytes apart.
+DM_HD void ray_fast_L(const uint8_t* planes, size_t plane_stride, int pitch, int rows, int cols, double sx, double sy, double dx,
+                      double dy, double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
+{
+    const uint8_t* Ep = planes + (size_t)slam_octant(dx, dy) * plane_stride;
     int i0, j0;
     unsigned e0;
     slam_ray_origin(Ep, pitch, rows, cols, sx, sy, &i0, &j0, &e0, reads);

@@ -474,6 +474,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     {
         // lane = particle; (64-particle block, beam segment) work items; see k_rays_pl
         a.grid = h->clr;
+        a.map_stride = slam_cone_plane_stride(h->rows, h->cols);
         const size_t cap_max = (size_t)64 << 20;  // 512 MiB of scratch at most
         const int64_t pblocks_all = cdiv(h->n, 64);
         int64_t pb_per_launch = (int64_t)(cap_max / ((size_t)B * 64));
@@ -541,6 +542,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     else if (h->prm.raycaster == SLAM_RAYCAST_FAST || h->prm.raycaster == SLAM_RAYCAST_FAST_BEAM_LANES)
     {
         a.grid = h->clr;
+        a.map_stride = slam_cone_plane_stride(h->rows, h->cols);
         hipLaunchKernelGGL(slamk::k_weights_L<0>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
     }
     else
@@ -939,13 +941,13 @@ SLAM_API int slam_mcl_set_map_u8(slam_mcl* h, const uint8_t* map, int32_t rows, 
     if (h->prm.mode != SLAM_MODE_LOCALIZATION) return fail(SLAM_ERR_STATE, "set_map_u8 is for localization mode");
     if (!map || rows != h->rows || cols != h->cols) return fail(SLAM_ERR_ARG, "map null or size differs from create()");
     const size_t bytes = (size_t)rows * cols;
-    const size_t pbytes = (size_t)(rows + 4) * (size_t)(cols + 4);  // clearance grid with its frame
+    const size_t pbytes = 8 * slam_cone_plane_stride(rows, cols);  // the 8 cone-clearance planes with their frames
     if (!h->grid)
     {
         if ((rc = dev_alloc(&h->grid, bytes)) || (rc = dev_alloc(&h->clr, pbytes))) return rc;
     }
     std::vector<uint8_t> E(pbytes);
-    slam_build_clearance_padded(map, rows, cols, E.data());
+    slam_build_cone_clearance_padded(map, rows, cols, E.data());
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->grid, map, bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->clr, E.data(), pbytes, hipMemcpyHostToDevice));

@@ -15,13 +15,18 @@ HH_API void hh_build_clearance(const uint8_t* map, int rows, int cols, uint8_t* 
     slam_build_clearance(map, rows, cols, E);
 }
 
-// E is the UNPADDED clearance grid in this harness' interface; the ray functions read the padded one.
-static std::vector<uint8_t> pad_grid(const uint8_t* E, int rows, int cols)
+// the 8 padded cone-clearance planes the kernels read (clearance.h), plane stride returned through *stride
+HH_API void hh_build_cone_planes(const uint8_t* map, int rows, int cols, uint8_t* planes)
 {
-    const size_t pitch = (size_t)cols + 4;
-    std::vector<uint8_t> Ep((size_t)(rows + 4) * pitch, 0);
-    for (int i = 0; i < rows; ++i) std::memcpy(Ep.data() + (size_t)(i + 2) * pitch + 2, E + (size_t)i * cols, cols);
-    return Ep;
+    slam_build_cone_clearance_padded(map, rows, cols, planes);
+}
+HH_API unsigned long hh_cone_plane_stride(int rows, int cols) { return (unsigned long)slam_cone_plane_stride(rows, cols); }
+
+static std::vector<uint8_t> cone_planes(const uint8_t* map, int rows, int cols)
+{
+    std::vector<uint8_t> P(8 * slam_cone_plane_stride(rows, cols));
+    slam_build_cone_clearance_padded(map, rows, cols, P.data());
+    return P;
 }
 
 // returns number of rays whose (hx, hy, hcell) differ bitwise between ray_fast_L and ray_walk.
@@ -37,7 +42,9 @@ HH_API long hh_rays_compare(const uint8_t* map, const uint8_t* E, int rows, int 
     int k_safe = (int)__builtin_floor(zmax) - 1;
     if (k_safe < 0) k_safe = 0;
     const int max_iter = (int)__builtin_ceil(zmax) + 8;
-    const std::vector<uint8_t> Ep = pad_grid(E, rows, cols);
+    const std::vector<uint8_t> Ep = cone_planes(map, rows, cols);
+    const size_t stride = slam_cone_plane_stride(rows, cols);
+    (void)E;
     for (long r = 0; r < n; ++r)
     {
         double s, c;
@@ -47,7 +54,7 @@ HH_API long hh_rays_compare(const uint8_t* map, const uint8_t* E, int rows, int 
         unsigned reads = 0;
         ray_walk<false, true>(const_cast<uint8_t*>(map), rows, cols, sx[r], sy[r], c, s, zmax2, zmax2, nullptr, nullptr,
                               max_iter, &a, &st);
-        ray_fast_L(Ep.data(), cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b, &reads);
+        ray_fast_L(Ep.data(), stride, cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b, &reads);
         *reads_fast += reads;
         *reads_walk += st.cells_read;
         if (out_hits)
@@ -95,20 +102,21 @@ HH_API long hh_advance_check(double x0, double y0, double dx, double dy, int tot
 }
 
 // per-ray number of clearance-grid reads of ray_fast_L (diagnostics for kernel tuning)
-HH_API void hh_fast_reads(const uint8_t* E, int rows, int cols, long n, const double* sx, const double* sy,
+HH_API void hh_fast_reads(const uint8_t* map, int rows, int cols, long n, const double* sx, const double* sy,
                           const double* theta, double zmax, int* reads_out)
 {
     const double zmax2 = zmax * zmax;
     int k_safe = (int)__builtin_floor(zmax) - 1;
     if (k_safe < 0) k_safe = 0;
-    const std::vector<uint8_t> Ep = pad_grid(E, rows, cols);
+    const std::vector<uint8_t> Ep = cone_planes(map, rows, cols);
+    const size_t stride = slam_cone_plane_stride(rows, cols);
     for (long r = 0; r < n; ++r)
     {
         double s, c;
         dm_sincos(theta[r], &s, &c);
         slam_ray_result b;
         unsigned reads = 0;
-        ray_fast_L(Ep.data(), cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b, &reads);
+        ray_fast_L(Ep.data(), stride, cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b, &reads);
         reads_out[r] = (int)reads;
     }
 }

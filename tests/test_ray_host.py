@@ -165,3 +165,33 @@ def test_ray_functions_under_address_and_ub_sanitizers(hh):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "mismatches 0 advance_mismatches 0" in out.stdout
+
+
+def test_cone_planes_equal_their_definition(hh):
+    """The 8 cone-clearance planes (slam_amd/csrc/clearance.h) against a brute-force evaluation of their
+    definition: smallest a such that a cell (a, b), 0 <= b <= a + 2, of the octant's cone is occupied or
+    outside the grid; stored as 0 for occupied cells and the frame, else max(1, min(255, a))."""
+    rng = np.random.default_rng(11)
+    hh.hh_cone_plane_stride.restype = ctypes.c_ulong
+    for rows, cols, density in [(23, 31, 0.03), (30, 17, 0.10), (9, 40, 0.0)]:
+        g = np.where(rng.random((rows, cols)) < density, 0, 255).astype(np.uint8)
+        stride = hh.hh_cone_plane_stride(rows, cols)
+        assert stride % 256 == 0 and stride >= (rows + 4) * (cols + 4)
+        planes = np.full(8 * stride, 7, dtype=np.uint8)
+        hh.hh_build_cone_planes(ptr(g), rows, cols, ptr(planes))
+        occ = lambda i, j: not (0 <= i < rows and 0 <= j < cols) or g[i, j] < 128
+        for o in range(8):
+            sx, sy = (-1 if o & 1 else 1), (-1 if o & 2 else 1)
+            (mi, mj), (ni, nj) = ((0, sx), (-sy, 0)) if not o & 4 else ((-sy, 0), (0, sx))  # image rows go down as y goes up
+            plane = planes[o * stride:o * stride + (rows + 4) * (cols + 4)].reshape(rows + 4, cols + 4)
+            assert not plane[:2].any() and not plane[-2:].any() and not plane[:, :2].any() and not plane[:, -2:].any()
+            for i in range(rows):
+                for j in range(cols):
+                    if occ(i, j):
+                        want = 0
+                    else:
+                        a = 0
+                        while not any(occ(i + a * mi + b * ni, j + a * mj + b * nj) for b in range(a + 3)):
+                            a += 1
+                        want = max(1, min(255, a))
+                    assert plane[i + 2, j + 2] == want, (rows, cols, o, i, j)
