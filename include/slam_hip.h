@@ -44,13 +44,17 @@ enum
     SLAM_RAYCAST_FAST = 0,                /* clearance-skipping search; kernel shape chosen by N */
     SLAM_RAYCAST_WALK = 1,                /* literal cell-by-cell walk (counts cells) */
     SLAM_RAYCAST_FAST_BEAM_LANES = 2,     /* force: one wavefront per particle, lanes over beams */
-    SLAM_RAYCAST_FAST_PARTICLE_LANES = 3, /* force: lane = particle, work item = (64 particles, beam segment) */
+    SLAM_RAYCAST_FAST_PARTICLE_LANES = 3, /* force: lane = particle, work item = (64 particles, beam segment), summed by a
+                                             second kernel in beam order */
     SLAM_RAYCAST_TWO_PHASE = 4,           /* SLAM mode, force: geometry of 64 rays at once (lane = beam), then the rays
                                              in order, 64 samples per pass (what SLAM_RAYCAST_FAST picks in SLAM mode
                                              below 262144 particles; 2 forces the older wave-per-ray form) */
-    SLAM_RAYCAST_TWO_PHASE_LITERAL = 5    /* test hook: the two-phase kernel with every batch of beams on its literal
+    SLAM_RAYCAST_TWO_PHASE_LITERAL = 5,   /* test hook: the two-phase kernel with every batch of beams on its literal
                                              fallback loop (taken by itself only when rounding makes a cell index move by
                                              two in one sample) */
+    SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT = 6 /* force: lane = particle, work item = 64 particles and the WHOLE scan; the
+                                             lane adds its beams' log-likelihoods itself, no scratch slab and no summing
+                                             kernel (what SLAM_RAYCAST_FAST picks from 524 288 particles per handle on) */
 };
 
 /* Construction parameters.  Zero-initialise, set struct_size = sizeof(slam_mcl_params), fill in.
@@ -161,7 +165,10 @@ int slam_mcl_get_stats(slam_mcl* h, int64_t out[3]);
  * reset: out[0] predict, [1] weights (the ray kernels), [2] resample (scan+select+gather), [3] sort, [4] map clone
  * (dense: the deep copy after the selection; tiles: table gather + census, and the copy-on-write copies made just
  * before the next weighting pass);
- * launches[k] = number of launches accumulated.  Enable with slam_mcl_profile(h, 1). */
+ * launches[k] = number of launches accumulated.  Enable with slam_mcl_profile(h, 1).  Every bracketed group costs
+ * two event records in the stream (about 10 us of idle GPU each); slam_mcl_profile(h, 2) times only out[1], and on
+ * the large-N localization path does so with a start event on the first and a stop event on the last kernel of the
+ * pass (hipExtLaunchKernel), i.e. without any record between the kernels. */
 int slam_mcl_profile(slam_mcl* h, int32_t enable);
 int slam_mcl_get_kernel_ms(slam_mcl* h, double ms[5], int64_t launches[5], int32_t reset);
 

@@ -17,6 +17,7 @@ WEIGHT_LINEAR, WEIGHT_LOG = 0, 1
 TILE_SIDE, TILE_BYTES = 64, 4096  # SLAM_TILE_SIDE, SLAM_TILE_BYTES of include/slam_hip.h
 MAPS_AUTO, MAPS_DENSE, MAPS_TILED = 0, 1, 2
 RAYCAST_FAST, RAYCAST_WALK, RAYCAST_FAST_BEAM_LANES, RAYCAST_FAST_PARTICLE_LANES, RAYCAST_TWO_PHASE, RAYCAST_TWO_PHASE_LITERAL = 0, 1, 2, 3, 4, 5
+RAYCAST_FAST_PARTICLE_LANES_DIRECT = 6
 
 
 class SlamError(RuntimeError):

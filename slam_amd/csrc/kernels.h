@@ -198,11 +198,16 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
 // (64-particle block, beam segment); the per-beam log-likelihoods go to a scratch slab
 // lw[block][beam][lane] (coalesced 512-byte stores) and k_sum_lw adds them per particle in beam
 // order, reproducing the sequential rounding of slam/mcl.cpp:69-74.
-template <int MIN_WAVES>
+// DIRECT (launches with one segment, i.e. enough particle blocks to fill the chip without cutting the beams): the lane
+// adds its particle's log-likelihoods itself, in beam order, and stores the weight: no slab, no k_sum_lw.
+template <int MIN_WAVES, bool DIRECT = false>
 __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
 {
     const int lane = threadIdx.x & 63;
     // (wave-uniform, and told so: beam index, scan entries and loop control then live in scalar registers)
+    // (workgroups go to the 8 XCDs round-robin.  Dealing each XCD a contiguous eighth of the segment-major items instead,
+    // so that one XCD walks one span of beam angles = one or two clearance planes, was measured: 0.79 vs 0.68 ms, the
+    // spans differ too much in work and the slowest XCD sets the time)
     const int64_t item = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // segment-major: the four wavefronts of a workgroup walk the same beams for neighbouring
     // (pose-sorted) particle blocks, i.e. the same map cells at about the same time
@@ -210,6 +215,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     if (seg >= a.nseg) return;  // whole wavefront
     const int64_t pb = item - (int64_t)seg * a.npblocks;
     int64_t p = a.p_first + pb * 64 + lane;
+    const bool real = p < a.n;
     if (p >= a.n) p = a.n - 1;  // padding lanes repeat the last particle; their values are never summed
     if (a.order) p = a.order[p];
     const double px = a.x[p], py = a.y[p], pth = a.th[p];
@@ -221,7 +227,8 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     const int i0 = slam_f2i(((double)a.rows - sy) - 1.0), j0 = slam_f2i(sx);
     const bool inb0 = slam_in_bounds(a.rows, a.cols, i0, j0);
     const unsigned off0 = inb0 ? (unsigned)(slam_mul24(i0, a.cols + 4) + j0 + 2 * (a.cols + 4) + 2) : 0u;  // (frame corner: 0)
-    double* slab = a.lw + (size_t)pb * (size_t)a.B * 64 + lane;
+    double* slab = DIRECT ? nullptr : a.lw + (size_t)pb * (size_t)a.B * 64 + lane;
+    double acc = 0.0;
     const int b0 = seg * a.seg_beams;
     const int b1 = (b0 + a.seg_beams) < a.B ? (b0 + a.seg_beams) : a.B;
     for (int b = b0; b < b1; ++b)
@@ -232,7 +239,11 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
         slam_ray_result r;
         const uint8_t* plane = a.grid + (size_t)slam_octant(c, s) * a.map_stride;
         ray_fast_L0(plane, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, i0, j0, plane[off0], &r, nullptr);
-        slab[(size_t)b * 64] = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
+        const double lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
+        if (DIRECT)
+            acc += lw;  // slam/mcl.cpp:69-74
+        else
+            slab[(size_t)b * 64] = lw;
         if (a.hit_xy)
         {
             const size_t o = (size_t)p * a.B + b;
@@ -241,6 +252,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
             a.hit_cell[o] = r.hcell;
         }
     }
+    if (DIRECT && real) a.w[p] = a.log_domain ? acc : dm_exp(acc);
 }
 
 // Pose-coherent order for k_rays_pl.  The weight of a particle does not depend on which lane

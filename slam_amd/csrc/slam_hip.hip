@@ -1,6 +1,7 @@
 // slam_hip.hip — C ABI (include/slam_hip.h) over the gfx950 kernels in kernels.h.
 // Compile with hipcc --offload-arch=gfx950 -ffp-contract=off (see slam_amd/build.py).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -138,7 +139,8 @@ struct slam_mcl
     int32_t *oident = nullptr, *order = nullptr;
     void* osort_tmp = nullptr;
     size_t osort_tmp_bytes = 0;
-    bool profile = false;
+    int profile = 0;  // 0 off, 1 every group (an event pair per group), 2 the weighting group only, on the kernels' own dispatch timestamps where the path allows
+    bool ext_timing = false;  // (set by do_weights while it times the pass through hipExtLaunchKernelGGL)
     std::vector<TimedSpan> spans;
     double acc_ms[G_COUNT] = {0, 0, 0, 0, 0};
     int64_t acc_launches[G_COUNT] = {0, 0, 0, 0, 0};
@@ -148,7 +150,7 @@ struct slam_mcl
         slam_mcl* h;
         TimedSpan s;
         bool on;
-        Span(slam_mcl* h_, int group) : h(h_), on(h_->profile)
+        Span(slam_mcl* h_, int group) : h(h_), on(h_->profile == 1 || (h_->profile == 2 && group == G_WEIGHTS && !h_->ext_timing))
         {
             if (!on) return;
             s.group = group;
@@ -254,6 +256,7 @@ struct Tuning
     int order_bits;  // SLAM_PL_ORDER_BITS: bits of the order key that are sorted
     int seg_beams;   // SLAM_PL_SEG: beams per work item (0 = chosen from the launch size)
     int waves;       // SLAM_PL_WAVES: wavefronts per SIMD the ray kernel is compiled for (4, 5, 6 or 8)
+    int direct_min;  // SLAM_PL_DIRECT_MIN: from this many 64-particle blocks on, the ray kernel sums the beams itself (no slab)
     int s_kernel;    // SLAM_S_KERNEL: 0 = default (two-phase SLAM-mode kernel), 1 = legacy wave-per-ray kernel,
                      // 2 = two-phase kernel with every batch on its literal fallback (tests)
 };
@@ -264,7 +267,7 @@ const Tuning& tuning()
         return v ? atoi(v) : dflt;
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
-                             env_int("SLAM_PL_WAVES", 5), env_int("SLAM_S_KERNEL", 0)};
+                             env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_S_KERNEL", 0)};
     return t;
 }
 
@@ -388,13 +391,25 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.luts = h->luts;
     const int order_mode = tuning().order_mode;
     const bool particle_lanes = !slam_mode && (h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES ||
+                                               h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT ||
                                                (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096));
     if (!(particle_lanes && order_mode > 0 && h->n >= 3))  // k_order_keys zeroes the counters itself
         HIPCHK(hipMemsetAsync(h->stats, 0, 3 * sizeof(unsigned long long), h->stream));
     // device time of the weighting kernels proper; tiled canvases first make their deferred copies
     // (the map clone of slam/mcl.cpp:147-155, accounted to that group)
+    // (profile level 2 on the particle-lane path: no event records in the stream, which cost ~10 us of idle GPU each;
+    // the first and the last kernel of the pass carry a start / a stop event on their own dispatch instead)
+    TimedSpan ext = {};
+    h->ext_timing = h->profile == 2 && particle_lanes;
+    if (h->ext_timing)
+    {
+        ext.group = G_WEIGHTS;
+        HIPCHK(hipEventCreate(&ext.a));
+        HIPCHK(hipEventCreate(&ext.b));
+    }
     std::unique_ptr<slam_mcl::Span> wspan;
     if (!(slam_mode && h->tiled)) wspan.reset(new slam_mcl::Span(h, G_WEIGHTS));
+    h->ext_timing = false;
     if (slam_mode)
     {
         a.grid = h->maps;
@@ -477,10 +492,13 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         a.map_stride = slam_cone_plane_stride(h->rows, h->cols);
         const size_t cap_max = (size_t)64 << 20;  // 512 MiB of scratch at most
         const int64_t pblocks_all = cdiv(h->n, 64);
+        // enough particle blocks to fill the chip several times over: one launch, whole scans per lane, no slab
+        const bool direct = h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT ||
+                            (h->prm.raycaster == SLAM_RAYCAST_FAST && pblocks_all >= tuning().direct_min);
         int64_t pb_per_launch = (int64_t)(cap_max / ((size_t)B * 64));
         if (pb_per_launch < 1) pb_per_launch = 1;
-        if (pb_per_launch > pblocks_all) pb_per_launch = pblocks_all;
-        const size_t need = (size_t)pb_per_launch * B * 64;
+        if (pb_per_launch > pblocks_all || direct) pb_per_launch = pblocks_all;
+        const size_t need = direct ? 0 : (size_t)pb_per_launch * B * 64;
         if (need > h->lw_cap)
         {
             hipFree(h->lw);
@@ -491,6 +509,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         }
         a.lw = h->lw;
         const int order_bits = tuning().order_bits;
+        bool ext_started = false;
         if (order_mode > 0)
         {
             if (!h->okeys)
@@ -507,8 +526,9 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 h->osort_tmp = tmp;
                 h->osort_tmp_bytes = bytes;
             }
-            hipLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x,
-                               h->y, h->th, order_mode, order_bits, h->okeys, h->oident, h->stats);
+            hipExtLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, ext.a, nullptr, 0, h->n,
+                                  h->x, h->y, h->th, order_mode, order_bits, h->okeys, h->oident, h->stats);
+            ext_started = true;
             size_t bytes = h->osort_tmp_bytes;
             HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, order_bits,
                                              h->stream));
@@ -525,19 +545,30 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             a.seg_beams = (int)cdiv(B, want);
             const int seg_env = tuning().seg_beams;
             if (seg_env > 0) a.seg_beams = seg_env < B ? seg_env : B;
+            if (direct) a.seg_beams = B;
             a.nseg = (int)cdiv(B, a.seg_beams);
             const dim3 grid((unsigned)cdiv(a.npblocks * a.nseg, 4));
             const int pl_waves = tuning().waves;
+            hipEvent_t ev_a = ext_started ? nullptr : ext.a;  // (null events: a plain launch)
+            ext_started = true;
+            if (direct)
+            {
+                hipExtLaunchKernelGGL((slamk::k_rays_pl<5, true>), grid, dim3(256), 0, h->stream, ev_a, ext.b, 0, a);
+                break;
+            }
             if (pl_waves >= 8)
-                hipLaunchKernelGGL(slamk::k_rays_pl<8>, grid, dim3(256), 0, h->stream, a);
+                hipExtLaunchKernelGGL(slamk::k_rays_pl<8>, grid, dim3(256), 0, h->stream, ev_a, nullptr, 0, a);
             else if (pl_waves >= 6)
-                hipLaunchKernelGGL(slamk::k_rays_pl<6>, grid, dim3(256), 0, h->stream, a);
+                hipExtLaunchKernelGGL(slamk::k_rays_pl<6>, grid, dim3(256), 0, h->stream, ev_a, nullptr, 0, a);
             else if (pl_waves >= 5)
-                hipLaunchKernelGGL(slamk::k_rays_pl<5>, grid, dim3(256), 0, h->stream, a);
+                hipExtLaunchKernelGGL(slamk::k_rays_pl<5>, grid, dim3(256), 0, h->stream, ev_a, nullptr, 0, a);
             else
-                hipLaunchKernelGGL(slamk::k_rays_pl<4>, grid, dim3(256), 0, h->stream, a);
-            hipLaunchKernelGGL(slamk::k_sum_lw, dim3((unsigned)cdiv(a.npblocks * 64, 256)), dim3(256), 0, h->stream, a);
+                hipExtLaunchKernelGGL(slamk::k_rays_pl<4>, grid, dim3(256), 0, h->stream, ev_a, nullptr, 0, a);
+            const bool last = pb0 + pb_per_launch >= pblocks_all;
+            hipExtLaunchKernelGGL(slamk::k_sum_lw, dim3((unsigned)cdiv(a.npblocks * 64, 256)), dim3(256), 0, h->stream, nullptr,
+                                  last ? ext.b : nullptr, 0, a);
         }
+        if (ext.a) h->spans.push_back(ext);
     }
     else if (h->prm.raycaster == SLAM_RAYCAST_FAST || h->prm.raycaster == SLAM_RAYCAST_FAST_BEAM_LANES)
     {
@@ -766,7 +797,10 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
         (int64_t)params->rows * params->cols >= 2147483647LL)
         return fail(SLAM_ERR_ARG, "rows/cols out of range");
     if (params->mode != SLAM_MODE_LOCALIZATION && params->mode != SLAM_MODE_SLAM) return fail(SLAM_ERR_ARG, "bad mode");
-    if (params->mode == SLAM_MODE_SLAM && params->raycaster == SLAM_RAYCAST_FAST && false) return SLAM_ERR_ARG;
+    if (params->raycaster < SLAM_RAYCAST_FAST || params->raycaster > SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT)
+        return fail(SLAM_ERR_ARG, "bad raycaster");
+    if (params->mode == SLAM_MODE_SLAM && params->raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT)
+        return fail(SLAM_ERR_ARG, "SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT is a localization-mode kernel shape");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (params->device < 0 || params->device >= ndev) return fail(SLAM_ERR_ARG, "device ordinal out of range");
@@ -1512,7 +1546,7 @@ SLAM_API int slam_mcl_get_stats(slam_mcl* h, int64_t out[3])
 SLAM_API int slam_mcl_profile(slam_mcl* h, int32_t enable)
 {
     if (!h) return fail(SLAM_ERR_ARG, "null handle");
-    h->profile = enable != 0;
+    h->profile = enable == 2 ? 2 : (enable != 0);
     return SLAM_OK;
 }
 

@@ -262,7 +262,9 @@ class Filter:
         return {"pool": int(out[0]), "live": int(out[1]), "allocated_since": int(out[2])}
 
     def profile(self, enable=True):
-        check(self.lib.slam_mcl_profile(self._h, 1 if enable else 0), self.lib)
+        """True / 1: an event pair around every kernel group; 2: the weighting pass only, timed on its kernels' own
+        dispatch timestamps where the path allows (no event records between the kernels); False / 0: off."""
+        check(self.lib.slam_mcl_profile(self._h, 2 if enable == 2 else (1 if enable else 0)), self.lib)
 
     def kernel_ms(self, reset=True):
         ms = np.zeros(5)

@@ -95,7 +95,7 @@ def test_gpu_reproduces_fixtures(V):
     # localization weights + hit cells (GL), every kernel shape
     gf = (orc.load_map("floor_plan") * 255).astype(np.uint8)
     x, y, th = V["gl_in"]
-    for rc in (capi.RAYCAST_FAST_BEAM_LANES, capi.RAYCAST_FAST_PARTICLE_LANES, capi.RAYCAST_WALK):
+    for rc in (capi.RAYCAST_FAST_BEAM_LANES, capi.RAYCAST_FAST_PARTICLE_LANES, capi.RAYCAST_FAST_PARTICLE_LANES_DIRECT, capi.RAYCAST_WALK):
         f = sa.Filter(96, *gf.shape, raycaster=rc)
         f.set_map(gf)
         f.set_poses(x, y, th)

@@ -264,6 +264,43 @@ def test_weights_degenerate_underflow_and_tiny_ranges(sa):
     f.close()
 
 
+def test_particle_lane_kernel_that_sums_its_own_beams(sa):
+    """SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT (what large handles get: no slab, no summing kernel) against the
+    segmented shape and the oracle, on a particle count that is no multiple of 64, in both weight domains."""
+    rng = np.random.default_rng(77)
+    g = grid_of("floor_plan")
+    rows, cols = g.shape
+    N, B = 5003, 77
+    x, y, th = cloud(rng, N, 640, 300)
+    x[:40] = rng.uniform(-30, cols + 30, 40)  # some from outside the grid and from inside walls
+    y[:40] = rng.uniform(-30, rows + 30, 40)
+    ang = np.linspace(-np.pi, np.pi, B, endpoint=False)
+    dist = rng.uniform(5.0, 400.0, B)
+    dist[::9] = 500.0
+    got = {}
+    for dom in (sa.capi.WEIGHT_LINEAR, sa.capi.WEIGHT_LOG):
+        for rc in (sa.capi.RAYCAST_FAST_PARTICLE_LANES_DIRECT, sa.capi.RAYCAST_FAST_PARTICLE_LANES):
+            f = sa.Filter(N, rows, cols, raycaster=rc, weight_domain=dom)
+            f.set_map(g)
+            f.set_poses(x, y, th)
+            f.record_hits(True)
+            f.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+            got[dom, rc] = (f.weights(), *f.hits())
+            f.close()
+        a, b = got[dom, sa.capi.RAYCAST_FAST_PARTICLE_LANES_DIRECT], got[dom, sa.capi.RAYCAST_FAST_PARTICLE_LANES]
+        assert_bits(a[0], b[0], "weights, two shapes")
+        assert_bits(a[1], b[1], "hit positions, two shapes")
+        assert np.array_equal(a[2], b[2])
+    sub = np.r_[0:64, rng.choice(N, 64, replace=False), N - 3:N]
+    ow, oxy, ocell, _ = orc.update_weights(x[sub], y[sub], th[sub], g, ang, dist, 5.0, 500.0, OFFSET, want_hits=True, math=orc.DET)
+    w, hxy, hcell = got[sa.capi.WEIGHT_LINEAR, sa.capi.RAYCAST_FAST_PARTICLE_LANES_DIRECT]
+    assert_bits(w[sub], ow, "weights vs oracle")
+    assert_bits(hxy[sub], oxy, "hit positions vs oracle")
+    assert np.array_equal(hcell[sub], ocell)
+    with pytest.raises(sa.SlamError):
+        sa.Filter(16, 64, 64, mode=sa.capi.MODE_SLAM, raycaster=sa.capi.RAYCAST_FAST_PARTICLE_LANES_DIRECT)
+
+
 # ---- K2b SLAM mode: raycast + likelihood + occupancy update ---------------------------------------
 S_SHAPES = {  # kernel shape -> (raycaster, canvas storage)
     "wave": ("RAYCAST_FAST_BEAM_LANES", "MAPS_DENSE"), "thread": ("RAYCAST_FAST_PARTICLE_LANES", "MAPS_DENSE"),
