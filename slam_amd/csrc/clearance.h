@@ -176,6 +176,10 @@ inline void slam_build_cone_plane(const uint8_t* occ, int R, int P, int oct, uin
 // The 8 planes in the padded layout the kernels read: plane k at planes + k * plane_stride, each
 // (rows+4) x (cols+4) bytes, cell (i,j) at (i+2)*(cols+4)+(j+2), frame = 0.
 inline size_t slam_cone_plane_stride(int rows, int cols) { return ((size_t)(rows + 4) * (size_t)(cols + 4) + 255) / 256 * 256; }
+// The kernels address the planes with 32-bit offsets.  A map too large for eight planes below 4 GiB (more than ~23 000
+// cells a side) gets ONE plane of Chebyshev clearance, valid for every octant (plane stride 0): more lookups per ray,
+// the same results.
+inline bool slam_cone_planes_fit(int rows, int cols) { return 8 * slam_cone_plane_stride(rows, cols) < ((size_t)1 << 32); }
 inline void slam_build_cone_clearance_padded(const uint8_t* map, int rows, int cols, uint8_t* planes)
 {
     const int R = rows + 4, P = cols + 4;

@@ -118,7 +118,7 @@ struct WeightArgs
     int64_t n;
     const double *x, *y, *th;
     uint8_t* grid;         // L/FAST: the 8 cone-clearance planes; L/WALK: raw map; S: per-particle maps
-    size_t map_stride;     // S mode: bytes between particle maps; L/FAST: bytes between clearance planes
+    size_t map_stride;     // S mode: bytes between particle maps; L/FAST: bytes between clearance planes (8 planes < 4 GiB; 0: one plane)
     int rows, cols, B;
     const double *angles, *z2, *z;  // per beam: angle, dist^2, sqrt(dist^2)
     double zmax2, zmax, stddev, norm, log_eps;
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
             dm_sincos(theta, &s, &c);
             slam_ray_result r;
             if (VARIANT == 0)
-                ray_fast_L(a.grid, a.map_stride, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr);
+                ray_fast_L(a.grid, (unsigned)a.map_stride, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr);
             else
                 ray_walk<false, true>(a.grid, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, nullptr, nullptr,
                                       a.max_iter, &r, &st);
@@ -237,8 +237,9 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
         double s, c;
         dm_sincos(theta, &s, &c);
         slam_ray_result r;
-        const uint8_t* plane = a.grid + (size_t)slam_octant(c, s) * a.map_stride;
-        ray_fast_L0(plane, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, i0, j0, plane[off0], &r, nullptr);
+        const unsigned plane_off = (unsigned)slam_octant(c, s) * (unsigned)a.map_stride;
+        ray_fast_L0(a.grid, plane_off, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, i0, j0, a.grid[off0 + plane_off],
+                    &r, nullptr);
         const double lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
         if (DIRECT)
             acc += lw;  // slam/mcl.cpp:69-74
@@ -262,8 +263,29 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
 // (11 bits per axis): far-apart particles that alias only cost coherence, never correctness.
 __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, const double* y, const double* th,
                                                     int mode, int key_bits, uint32_t* keys, int32_t* ident,
-                                                    unsigned long long* stats)
+                                                    unsigned long long* stats, const double* scan_src, double* scan_dst,
+                                                    int scan_n)
 {
+    // side job of the last workgroup: the new scan from its pinned host slot to the device (read by the kernels that
+    // follow on the stream; saves the copy kernel and its launch gap)
+    // (eight independent loads per thread in flight: the reads cross PCIe, one round trip instead of eight)
+    if (blockIdx.x == gridDim.x - 1)
+        for (int base = 0; base < scan_n; base += 8 * (int)blockDim.x)
+        {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
+                v[u] = i < scan_n ? __builtin_nontemporal_load(scan_src + i) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
+                if (i < scan_n) scan_dst[i] = v[u];
+            }
+        }
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     if (p < 3) stats[p] = 0;  // the pass's counters start at zero (saves a memset launch)
@@ -935,7 +957,10 @@ __global__ void __launch_bounds__(256) k_clone_maps(const uint8_t* maps, uint8_t
 // thousands of tables share (1.6 ms in the first version), and a rule of thumb (ownership survives
 // only in a sole child) leaves exclusive tiles unowned, which costs copies and pool space.
 // (Letting one of several children inherit the ownership is NOT valid: it would write in place a
-// tile its siblings still reference outside their own sensor range.)
+// tile its siblings still reference outside their own sensor range.  Letting the LAST sibling that
+// leaves a tile keep it IS valid, with a per-tile count of the siblings that have copied it; it was
+// built and measured in round 2: the weights of a grid-SLAM filter are so peaked that a family has
+// ~20 members, so it saved 4.5 % of the copies, and it was taken out again.)
 __global__ void __launch_bounds__(256) k_tab_gather(const int32_t* tab, int32_t* tab2, const int32_t* src, int T, int* ref,
                                                     int* who, int live)
 {

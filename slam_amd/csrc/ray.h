@@ -241,14 +241,14 @@ DM_HD void slam_advance(slam_axis* X, slam_axis* Y, double dx, double dy, int m)
 //
 // The start cell of a ray (the same for every beam of a particle) and its clearance in the plane of the
 // ray's octant (0 when the origin is outside the grid).
-DM_HD void slam_ray_origin(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, int* i0, int* j0,
-                           unsigned* e0, unsigned* reads)
+DM_HD void slam_ray_origin(const uint8_t* Ep, unsigned plane_off, int pitch, int rows, int cols, double sx, double sy, int* i0,
+                           int* j0, unsigned* e0, unsigned* reads)
 {
     const int i = slam_f2i(((double)rows - sy) - 1.0), j = slam_f2i(sx);
     unsigned e = 0;
     if (slam_in_bounds(rows, cols, i, j))
     {
-        e = Ep[(unsigned)(slam_mul24(i, pitch) + j + 2 * pitch + 2)];
+        e = Ep[(unsigned)(slam_mul24(i, pitch) + j + 2 * pitch + 2) + plane_off];
         if (reads) ++*reads;
     }
     *i0 = i;
@@ -256,13 +256,16 @@ DM_HD void slam_ray_origin(const uint8_t* Ep, int pitch, int rows, int cols, dou
     *e0 = e;
 }
 
-DM_HD void ray_fast_L0(const uint8_t* Ep, int pitch, int rows, int cols, double sx, double sy, double dx, double dy,
-                       double zmax2, int k_safe, int i0, int j0, unsigned e0, slam_ray_result* res, unsigned* reads)
+// Ep = the first plane, plane_off = byte offset of the ray's plane: every read is Ep[32-bit offset], which on the
+// device is one load with a scalar base and a 32-bit lane offset (the planes together stay below 4 GiB, see
+// slam_cone_planes_fit).
+DM_HD void ray_fast_L0(const uint8_t* Ep, unsigned plane_off, int pitch, int rows, int cols, double sx, double sy, double dx,
+                       double dy, double zmax2, int k_safe, int i0, int j0, unsigned e0, slam_ray_result* res, unsigned* reads)
 {
     res->hx = -1.0;
     res->hy = -1.0;
     res->hcell = -1;
-    const int org = 2 * pitch + 2;  // cell (0,0)
+    const unsigned org = plane_off + 2u * (unsigned)pitch + 2u;  // cell (0,0) (offsets wrap modulo 2^32: frame cells lie before it)
     const double rows_d = (double)rows;
     // accumulated rounding stays far below the distance margin only for moderate coordinates;
     // anything farther out starts (and stays) outside every supported grid: literal loop only.
@@ -292,7 +295,7 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, int pitch, int rows, int cols, double 
         if (i != ci0 || j != cj0)
         {
             if (!slam_in_bounds(rows, cols, i, j)) return;  // slam/raycast.cpp:176
-            e = Ep[(unsigned)(slam_mul24(i, pitch) + j + org)];
+            e = Ep[(unsigned)(slam_mul24(i, pitch) + j) + org];
             if (reads) ++*reads;
             if (e == 0)
             {  // slam/raycast.cpp:183-189
@@ -368,7 +371,7 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, int pitch, int rows, int cols, double 
 #ifdef SLAM_RAY_DEBUG
             if (i < -2 || i > rows + 1 || j < -2 || j > cols + 1) __builtin_trap();  // frame guarantee violated
 #endif
-            e = Ep[(unsigned)(slam_mul24(i, pitch) + j + org)];
+            e = Ep[(unsigned)(slam_mul24(i, pitch) + j) + org];
             if (reads) ++*reads;
             if (e == 0 || last) break;
         }
@@ -395,7 +398,7 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, int pitch, int rows, int cols, double 
         if (i == pi && j == pj) continue;
         if (!slam_in_bounds(rows, cols, i, j)) return;
         if (reads) ++*reads;
-        if (Ep[(unsigned)(slam_mul24(i, pitch) + j + org)] == 0)
+        if (Ep[(unsigned)(slam_mul24(i, pitch) + j) + org] == 0)
         {
             res->hx = x;
             res->hy = y;
@@ -415,15 +418,15 @@ DM_HD int slam_octant(double dx, double dy)
     return (dx < 0.0 ? 1 : 0) | (dy < 0.0 ? 2 : 0) | (dm_fabs(dx) < dm_fabs(dy) ? 4 : 0);
 }
 
-// planes: the 8 cone-clearance planes, plane_stride bytes apart.
-DM_HD void ray_fast_L(const uint8_t* planes, size_t plane_stride, int pitch, int rows, int cols, double sx, double sy, double dx,
+// planes: the 8 cone-clearance planes, plane_stride bytes apart (0: one Chebyshev-clearance plane serves every octant).
+DM_HD void ray_fast_L(const uint8_t* planes, unsigned plane_stride, int pitch, int rows, int cols, double sx, double sy, double dx,
                       double dy, double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
 {
-    const uint8_t* Ep = planes + (size_t)slam_octant(dx, dy) * plane_stride;
+    const unsigned plane_off = (unsigned)slam_octant(dx, dy) * plane_stride;
     int i0, j0;
     unsigned e0;
-    slam_ray_origin(Ep, pitch, rows, cols, sx, sy, &i0, &j0, &e0, reads);
-    ray_fast_L0(Ep, pitch, rows, cols, sx, sy, dx, dy, zmax2, k_safe, i0, j0, e0, res, reads);
+    slam_ray_origin(planes, plane_off, pitch, rows, cols, sx, sy, &i0, &j0, &e0, reads);
+    ray_fast_L0(planes, plane_off, pitch, rows, cols, sx, sy, dx, dy, zmax2, k_safe, i0, j0, e0, res, reads);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -78,7 +78,8 @@ struct slam_mcl
         th = state + 2 * n;
         w = state + 3 * n;
     }
-    uint8_t *grid = nullptr, *clr = nullptr;     // localization: raw map + clearance grid
+    uint8_t *grid = nullptr, *clr = nullptr;     // localization: raw map + clearance planes
+    size_t clr_stride = 0;                       // bytes between the 8 cone planes (0: one Chebyshev plane)
     uint8_t *maps = nullptr, *maps2 = nullptr;   // SLAM: per-particle canvases
     uint8_t* luts = nullptr;
     bool have_map = false;
@@ -108,12 +109,18 @@ struct slam_mcl
     double* scan_dev = nullptr;  // [angle | dist^2 | sqrt(dist^2)], Bcap doubles each (packed at B)
     double *angles = nullptr, *z2 = nullptr, *z = nullptr;
     std::vector<double> scan_cache;
-    // pinned staging ring of the scan upload: a copy from pageable memory would make the host wait for
-    // the stream to drain on every update; slot k is reused once its own copy has run
-    enum { SCAN_RING = 4 };
-    double* scan_pin[SCAN_RING] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t scan_ev[SCAN_RING] = {nullptr, nullptr, nullptr, nullptr};
-    int scan_slot = 0;
+    // pinned staging ring of the scan upload: a copy from pageable memory would make the host wait for the stream to
+    // drain on every update.  The slots form groups of SCAN_GROUP; one event per group, recorded behind the consumer
+    // of the group's last slot and waited for when the ring comes round to the group again (an event record costs
+    // ~10 us of idle GPU: one per update was 1 % of a headline step).  A filled slot stays `scan_pending` until
+    // do_weights either hands it to k_order_keys (which copies it to scan_dev as a side job: no copy kernel at all) or
+    // copies it itself.
+    enum { SCAN_RING = 8, SCAN_GROUP = 4 };
+    double* scan_pin[SCAN_RING] = {};
+    hipEvent_t scan_ev[SCAN_RING / SCAN_GROUP] = {};
+    int scan_slot = SCAN_RING - 1;
+    const double* scan_pending = nullptr;  // pinned slot whose content scan_dev does not hold yet
+    size_t scan_pending_n = 0;
     int last_B = 0;
     // noise
     double *inj_normals = nullptr, *inj_uniforms = nullptr;
@@ -208,6 +215,31 @@ int finish(slam_mcl* h)
     return SLAM_OK;
 }
 
+// Tuning knobs of the particle-lane weighting pass, read once from the environment (experiments and
+// tools/; the defaults are what the measurements in DESIGN.md chose).
+struct Tuning
+{
+    int order_mode;  // SLAM_PL_ORDER: 0 = no pose-coherent order, else kind | (tile_shift + 1) << 4 | heading_bits << 8
+    int order_bits;  // SLAM_PL_ORDER_BITS: bits of the order key that are sorted
+    int seg_beams;   // SLAM_PL_SEG: beams per work item (0 = chosen from the launch size)
+    int waves;       // SLAM_PL_WAVES: wavefronts per SIMD the ray kernel is compiled for (4, 5, 6 or 8)
+    int direct_min;  // SLAM_PL_DIRECT_MIN: from this many 64-particle blocks on, the ray kernel sums the beams itself (no slab)
+    int cone_planes; // SLAM_CONE_PLANES: 1 = per-octant cone-clearance planes (default), 0 = one Chebyshev-clearance plane
+    int scan_fuse;   // SLAM_SCAN_FUSE: 1 = k_order_keys copies the new scan from its pinned slot (default), 0 = a copy of its own
+    int s_kernel;    // SLAM_S_KERNEL: 0 = default (two-phase SLAM-mode kernel), 1 = legacy wave-per-ray kernel,
+                     // 2 = two-phase kernel with every batch on its literal fallback (tests)
+};
+const Tuning& tuning()
+{
+    auto env_int = [](const char* name, int dflt) {
+        const char* v = getenv(name);
+        return v ? atoi(v) : dflt;
+    };
+    static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
+                             env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0)};
+    return t;
+}
+
 // SLAM_MAPS_TILED: new tables (src != nullptr: table p = old table src[p]), census of the tiles (who
 // owns what, exactly), free list of the unreferenced ones, allocation cursor restarted.
 int tile_collect(slam_mcl* h, const int32_t* src)
@@ -248,29 +280,6 @@ void build_luts(uint8_t* t)
     }
 }
 
-// Tuning knobs of the particle-lane weighting pass, read once from the environment (experiments and
-// tools/; the defaults are what the measurements in DESIGN.md chose).
-struct Tuning
-{
-    int order_mode;  // SLAM_PL_ORDER: 0 = no pose-coherent order, else kind | (tile_shift + 1) << 4 | heading_bits << 8
-    int order_bits;  // SLAM_PL_ORDER_BITS: bits of the order key that are sorted
-    int seg_beams;   // SLAM_PL_SEG: beams per work item (0 = chosen from the launch size)
-    int waves;       // SLAM_PL_WAVES: wavefronts per SIMD the ray kernel is compiled for (4, 5, 6 or 8)
-    int direct_min;  // SLAM_PL_DIRECT_MIN: from this many 64-particle blocks on, the ray kernel sums the beams itself (no slab)
-    int s_kernel;    // SLAM_S_KERNEL: 0 = default (two-phase SLAM-mode kernel), 1 = legacy wave-per-ray kernel,
-                     // 2 = two-phase kernel with every batch on its literal fallback (tests)
-};
-const Tuning& tuning()
-{
-    auto env_int = [](const char* name, int dflt) {
-        const char* v = getenv(name);
-        return v ? atoi(v) : dflt;
-    };
-    static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
-                             env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_S_KERNEL", 0)};
-    return t;
-}
-
 int check_handle(slam_mcl* h)
 {
     if (!h) return fail(SLAM_ERR_ARG, "null handle");
@@ -297,8 +306,10 @@ int upload_scan(slam_mcl* h, const double* angles, const double* dists, int B)
             if (h->scan_pin[k]) hipHostFree(h->scan_pin[k]);
             h->scan_pin[k] = nullptr;
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->scan_pin[k]), sizeof(double) * 3 * (size_t)B, hipHostMallocDefault));
-            if (!h->scan_ev[k]) HIPCHK(hipEventCreateWithFlags(&h->scan_ev[k], hipEventDisableTiming));
         }
+        for (int g = 0; g < slam_mcl::SCAN_RING / slam_mcl::SCAN_GROUP; ++g)
+            if (!h->scan_ev[g]) HIPCHK(hipEventCreateWithFlags(&h->scan_ev[g], hipEventDisableTiming));
+        h->scan_pending = nullptr;
         h->Bcap = B;
         h->scan_cache.clear();
     }
@@ -315,16 +326,34 @@ int upload_scan(slam_mcl* h, const double* angles, const double* dists, int B)
     h->z2 = h->scan_dev + B;
     h->z = h->scan_dev + 2 * (size_t)B;
     if (h->last_B == B && h->scan_cache == pack) return SLAM_OK;  // same scan re-applied (benchmark/mcl.cpp:58-64)
-    // stream-ordered copy out of a pinned slot: kernels already queued on the stream still see the
-    // old scan, and the host does not wait for them
-    const int k = h->scan_slot = (h->scan_slot + 1) % slam_mcl::SCAN_RING;
-    HIPCHK(hipEventSynchronize(h->scan_ev[k]));  // the copy that last used this slot (four uploads ago) has run
+    // into the next pinned slot; kernels already queued on the stream still see the old scan in scan_dev, and the host
+    // does not wait for them
+    // (a slot that was filled but never consumed, after a failed update, has no reader on the stream: it is filled again)
+    const int k = h->scan_pending ? h->scan_slot : (h->scan_slot = (h->scan_slot + 1) % slam_mcl::SCAN_RING);
+    if (k % slam_mcl::SCAN_GROUP == 0 && !h->scan_pending)
+        HIPCHK(hipEventSynchronize(h->scan_ev[k / slam_mcl::SCAN_GROUP]));  // the group's slots (24+ uploads ago) have been consumed
     std::memcpy(h->scan_pin[k], pack.data(), sizeof(double) * 3 * (size_t)B);
-    HIPCHK(hipMemcpyAsync(h->scan_dev, h->scan_pin[k], sizeof(double) * 3 * (size_t)B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipEventRecord(h->scan_ev[k], h->stream));
+    h->scan_pending = h->scan_pin[k];
+    h->scan_pending_n = 3 * (size_t)B;
     h->scan_cache.swap(pack);
     h->last_B = B;
     return SLAM_OK;
+}
+
+// Called behind the launch (or copy) that reads the pending slot.
+int scan_consumed(slam_mcl* h)
+{
+    h->scan_pending = nullptr;
+    if (h->scan_slot % slam_mcl::SCAN_GROUP == slam_mcl::SCAN_GROUP - 1)
+        HIPCHK(hipEventRecord(h->scan_ev[h->scan_slot / slam_mcl::SCAN_GROUP], h->stream));
+    return SLAM_OK;
+}
+
+int flush_scan(slam_mcl* h)
+{
+    if (!h->scan_pending) return SLAM_OK;
+    HIPCHK(hipMemcpyAsync(h->scan_dev, h->scan_pending, sizeof(double) * h->scan_pending_n, hipMemcpyHostToDevice, h->stream));
+    return scan_consumed(h);
 }
 
 int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double off[3])
@@ -395,6 +424,11 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                                                (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096));
     if (!(particle_lanes && order_mode > 0 && h->n >= 3))  // k_order_keys zeroes the counters itself
         HIPCHK(hipMemsetAsync(h->stats, 0, 3 * sizeof(unsigned long long), h->stream));
+    if (!(particle_lanes && order_mode > 0 && tuning().scan_fuse))  // k_order_keys also brings the new scan to scan_dev
+    {
+        int rc = flush_scan(h);
+        if (rc) return rc;
+    }
     // device time of the weighting kernels proper; tiled canvases first make their deferred copies
     // (the map clone of slam/mcl.cpp:147-155, accounted to that group)
     // (profile level 2 on the particle-lane path: no event records in the stream, which cost ~10 us of idle GPU each;
@@ -489,7 +523,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     {
         // lane = particle; (64-particle block, beam segment) work items; see k_rays_pl
         a.grid = h->clr;
-        a.map_stride = slam_cone_plane_stride(h->rows, h->cols);
+        a.map_stride = h->clr_stride;
         const size_t cap_max = (size_t)64 << 20;  // 512 MiB of scratch at most
         const int64_t pblocks_all = cdiv(h->n, 64);
         // enough particle blocks to fill the chip several times over: one launch, whole scans per lane, no slab
@@ -527,8 +561,14 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 h->osort_tmp_bytes = bytes;
             }
             hipExtLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, ext.a, nullptr, 0, h->n,
-                                  h->x, h->y, h->th, order_mode, order_bits, h->okeys, h->oident, h->stats);
+                                  h->x, h->y, h->th, order_mode, order_bits, h->okeys, h->oident, h->stats, h->scan_pending,
+                                  h->scan_dev, (int)(h->scan_pending ? h->scan_pending_n : 0));
             ext_started = true;
+            if (h->scan_pending)
+            {
+                int rc = scan_consumed(h);
+                if (rc) return rc;
+            }
             size_t bytes = h->osort_tmp_bytes;
             HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, order_bits,
                                              h->stream));
@@ -573,7 +613,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     else if (h->prm.raycaster == SLAM_RAYCAST_FAST || h->prm.raycaster == SLAM_RAYCAST_FAST_BEAM_LANES)
     {
         a.grid = h->clr;
-        a.map_stride = slam_cone_plane_stride(h->rows, h->cols);
+        a.map_stride = h->clr_stride;
         hipLaunchKernelGGL(slamk::k_weights_L<0>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
     }
     else
@@ -772,10 +812,9 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (int k = 0; k < slam_mcl::SCAN_RING; ++k)
-    {
         if (h->scan_pin[k]) hipHostFree(h->scan_pin[k]);
-        if (h->scan_ev[k]) hipEventDestroy(h->scan_ev[k]);
-    }
+    for (int g = 0; g < slam_mcl::SCAN_RING / slam_mcl::SCAN_GROUP; ++g)
+        if (h->scan_ev[g]) hipEventDestroy(h->scan_ev[g]);
     for (size_t l = 0; l < h->lvl_s.size(); ++l)
     {
         if (h->lvl_s[l]) hipFree(h->lvl_s[l]);
@@ -975,13 +1014,20 @@ SLAM_API int slam_mcl_set_map_u8(slam_mcl* h, const uint8_t* map, int32_t rows, 
     if (h->prm.mode != SLAM_MODE_LOCALIZATION) return fail(SLAM_ERR_STATE, "set_map_u8 is for localization mode");
     if (!map || rows != h->rows || cols != h->cols) return fail(SLAM_ERR_ARG, "map null or size differs from create()");
     const size_t bytes = (size_t)rows * cols;
-    const size_t pbytes = 8 * slam_cone_plane_stride(rows, cols);  // the 8 cone-clearance planes with their frames
+    // the 8 cone-clearance planes with their frames, or ONE Chebyshev plane (a map too large for 32-bit plane offsets;
+    // SLAM_CONE_PLANES=0 forces it: tests)
+    const bool cone = slam_cone_planes_fit(rows, cols) && tuning().cone_planes;
+    h->clr_stride = cone ? slam_cone_plane_stride(rows, cols) : 0;
+    const size_t pbytes = cone ? 8 * h->clr_stride : (size_t)(rows + 4) * (size_t)(cols + 4);
     if (!h->grid)
     {
         if ((rc = dev_alloc(&h->grid, bytes)) || (rc = dev_alloc(&h->clr, pbytes))) return rc;
     }
     std::vector<uint8_t> E(pbytes);
-    slam_build_cone_clearance_padded(map, rows, cols, E.data());
+    if (cone)
+        slam_build_cone_clearance_padded(map, rows, cols, E.data());
+    else
+        slam_build_clearance_padded(map, rows, cols, E.data());
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->grid, map, bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->clr, E.data(), pbytes, hipMemcpyHostToDevice));

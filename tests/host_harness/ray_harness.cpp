@@ -44,17 +44,21 @@ HH_API long hh_rays_compare(const uint8_t* map, const uint8_t* E, int rows, int 
     const int max_iter = (int)__builtin_ceil(zmax) + 8;
     const std::vector<uint8_t> Ep = cone_planes(map, rows, cols);
     const size_t stride = slam_cone_plane_stride(rows, cols);
-    (void)E;
+    // E (the unpadded Chebyshev clearance) in the padded layout: the one-plane form the library falls back to for
+    // maps too large for 32-bit plane offsets (plane stride 0); checked on every ray as well
+    std::vector<uint8_t> Ec((size_t)(rows + 4) * (cols + 4), 0);
+    for (int i = 0; i < rows; ++i) std::memcpy(Ec.data() + (size_t)(i + 2) * (cols + 4) + 2, E + (size_t)i * cols, cols);
     for (long r = 0; r < n; ++r)
     {
         double s, c;
         dm_sincos(theta[r], &s, &c);
-        slam_ray_result a, b;
+        slam_ray_result a, b, b1;
+        ray_fast_L(Ec.data(), 0u, cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b1, nullptr);
         slam_ray_stats st = {0, 0, 0};
         unsigned reads = 0;
         ray_walk<false, true>(const_cast<uint8_t*>(map), rows, cols, sx[r], sy[r], c, s, zmax2, zmax2, nullptr, nullptr,
                               max_iter, &a, &st);
-        ray_fast_L(Ep.data(), stride, cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b, &reads);
+        ray_fast_L(Ep.data(), (unsigned)stride, cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b, &reads);
         *reads_fast += reads;
         *reads_walk += st.cells_read;
         if (out_hits)
@@ -62,7 +66,8 @@ HH_API long hh_rays_compare(const uint8_t* map, const uint8_t* E, int rows, int 
             out_hits[2 * r] = a.hx;
             out_hits[2 * r + 1] = a.hy;
         }
-        if (std::memcmp(&a.hx, &b.hx, 8) || std::memcmp(&a.hy, &b.hy, 8) || a.hcell != b.hcell)
+        if (std::memcmp(&a.hx, &b.hx, 8) || std::memcmp(&a.hy, &b.hy, 8) || a.hcell != b.hcell ||
+            std::memcmp(&a.hx, &b1.hx, 8) || std::memcmp(&a.hy, &b1.hy, 8) || a.hcell != b1.hcell)
         {
             if (!bad) *first_bad = r;
             ++bad;
@@ -116,7 +121,7 @@ HH_API void hh_fast_reads(const uint8_t* map, int rows, int cols, long n, const 
         dm_sincos(theta[r], &s, &c);
         slam_ray_result b;
         unsigned reads = 0;
-        ray_fast_L(Ep.data(), stride, cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b, &reads);
+        ray_fast_L(Ep.data(), (unsigned)stride, cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b, &reads);
         reads_out[r] = (int)reads;
     }
 }

@@ -7,6 +7,7 @@ functions as the kernels) EVERYTHING is compared bit for bit, weights and poses 
 its glibc mode (what the reference calls) the integer results are compared exactly and the
 floating-point ones with the stated tolerance.
 """
+import os
 import zlib
 
 import numpy as np
@@ -15,6 +16,7 @@ import pytest
 import _oracle as orc
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 REL_TOL = 1e-5  # north_star tolerance for weights and poses
 ODOM = [2.5, 0.02, 0.02]            # benchmark/mcl.cpp:60
@@ -299,6 +301,48 @@ def test_particle_lane_kernel_that_sums_its_own_beams(sa):
     assert np.array_equal(hcell[sub], ocell)
     with pytest.raises(sa.SlamError):
         sa.Filter(16, 64, 64, mode=sa.capi.MODE_SLAM, raycaster=sa.capi.RAYCAST_FAST_PARTICLE_LANES_DIRECT)
+
+
+def test_one_chebyshev_plane_in_place_of_the_cone_planes(sa, tmp_path):
+    """Maps too large for eight planes below 4 GiB get ONE plane of Chebyshev clearance (plane stride 0).  The choice is
+    made when the map is set; SLAM_CONE_PLANES=0 forces it in a child process, whose weights and hits must equal the ones
+    computed here with the cone planes, in both kernel shapes."""
+    import subprocess
+    import sys
+
+    code = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import _oracle as orc, slam_amd as sa
+rng = np.random.default_rng(303)
+g = (orc.load_map("floor_plan") * 255).astype(np.uint8)
+rows, cols = g.shape
+N, B = 4500, 40
+x, y, th = rng.uniform(-20, cols + 20, N), rng.uniform(-20, rows + 20, N), rng.uniform(-4, 4, N)
+ang = np.linspace(-np.pi, np.pi, B, endpoint=False); dist = rng.uniform(3.0, 480.0, B)
+out = {}
+for name, rc in (("pl", sa.capi.RAYCAST_FAST_PARTICLE_LANES), ("bl", sa.capi.RAYCAST_FAST_BEAM_LANES)):
+    f = sa.Filter(N, rows, cols, raycaster=rc); f.set_map(g); f.set_poses(x, y, th); f.record_hits(True)
+    f.update_weights(ang, dist, 5.0, 500.0, [0.0, 30.0, 0.0])
+    hxy, hc = f.hits()
+    out[name + "_w"], out[name + "_xy"], out[name + "_c"] = f.weights(), hxy, hc
+    f.close()
+np.savez(sys.argv[3], **out)
+"""
+    root = os.path.dirname(HERE)
+    res = {}
+    for planes in ("1", "0"):
+        path = str(tmp_path / f"planes{planes}.npz")
+        env = dict(os.environ, SLAM_CONE_PLANES=planes)
+        subprocess.run([sys.executable, "-c", code, root, HERE, path], check=True, env=env, timeout=300)
+        res[planes] = np.load(path)
+    for k in res["1"].files:
+        a, b = res["1"][k], res["0"][k]
+        if a.dtype == np.float64:
+            assert_bits(a, b, k)
+        else:
+            assert np.array_equal(a, b), k
+    assert (res["1"]["pl_c"] >= 0).mean() > 0.5
 
 
 # ---- K2b SLAM mode: raycast + likelihood + occupancy update ---------------------------------------
