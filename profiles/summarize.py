@@ -17,30 +17,77 @@ def kernel_stats(db):
     return "\n".join(out)
 
 
-def timed_region(db, steps=20):
-    """What bench.py's HIP events bracket: per kernel the average over the LAST `steps` launches (the
-    timed steps; rocprofv3's own averages include the warm-up steps, whose wide cloud makes them slower),
-    and the weighting pass as one span, from the start of k_order_keys to the end of k_sum_lw."""
+def timed_region(db, steps=20, after=20):
+    """What bench.py's timed region holds: per kernel the average over the `steps` launches per step-kernel that come
+    before the last `after` steps (bench.py runs the timed steps, then `after` more with every group bracketed by
+    events; rocprofv3's own averages also include the warm-up steps, whose wide cloud makes them slower), and the
+    weighting pass as one span, from the start of k_order_keys to the end of k_sum_lw."""
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, start, end from kernels order by start").fetchall()
     by = {}
     for n, a, b in rows:
         by.setdefault(n, []).append((a, b))
-    out = ["%-90s %8s %12s" % (f"kernel (last {steps} steps)", "launches", "avg_ns")]
-    per_step = {n: len(v) // max(len(by.get(next((k for k in by if "k_sum_lw" in k), n), [])), 1) for n, v in by.items()}
+    out = ["%-90s %8s %12s" % (f"kernel (the {steps} timed steps)", "launches", "avg_ns")]
+    n_steps = len(next((v for k, v in by.items() if "k_sum_lw" in k), [])) or 1
     for n, v in sorted(by.items(), key=lambda kv: -sum(b - a for a, b in kv[1])):
-        k = max(per_step.get(n, 1), 1) * steps
-        if len(v) < k:
+        per = len(v) // n_steps
+        if per < 1 or len(v) < per * (steps + after):
             continue
-        tail = v[-k:]
-        out.append("%-90s %8d %12.0f" % (n[:90], len(tail), sum(b - a for a, b in tail) / len(tail)))
+        sel = v[len(v) - per * (steps + after):len(v) - per * after]
+        out.append("%-90s %8d %12.0f" % (n[:90], len(sel), sum(b - a for a, b in sel) / len(sel)))
     keys = [v for n, v in by.items() if "k_order_keys" in n]
     sums = [v for n, v in by.items() if "k_sum_lw" in n]
-    if keys and sums and len(keys[0]) == len(sums[0]) >= steps:
-        spans = [e[1] - s[0] for s, e in zip(keys[0][-steps:], sums[0][-steps:])]
+    if keys and sums and len(keys[0]) == len(sums[0]) >= steps + after:
+        k0, s0 = keys[0][-(steps + after):-after], sums[0][-(steps + after):-after]
+        spans = [e[1] - s[0] for s, e in zip(k0, s0)]
         out.append("weighting pass, start of k_order_keys to end of k_sum_lw (= roofline.kernel_avg_ms of bench.py): "
                    "avg %.0f ns over %d steps, min %d, max %d" % (sum(spans) / len(spans), len(spans), min(spans), max(spans)))
+        first, last = keys[0][-(steps + after)][0], sums[0][-after - 1][1]
+        busy = sum(b - a for n, v in by.items() for a, b in v if a >= first and b <= last)
+        out.append("timed region on the device: %.1f us per step from the first k_order_keys to the last k_sum_lw, kernels busy %.1f us "
+                   "per step" % ((last - first) / steps / 1e3, busy / steps / 1e3))
     return "\n".join(out)
+
+
+def slam_summary(base, tag):
+    """profiles/rocprof_<tag>_slam.txt: the grid-SLAM kernels of the 125 000-particle entry (the launches of
+    k_weights_S2 with the largest grid, and every tile kernel between the first and the last of them)."""
+    lines = [f"# rocprofv3 summary of the grid-SLAM kernels, tag {tag} (profiles/run_profile.sh: trace pass 2 = bench.py --no-cpu-baseline with all",
+             "# secondary entries; counter passes = bench.py --steps 10 --warmup 3 --no-cpu-baseline with BENCH_SECONDARY=slam125k).",
+             "# 125 000 particles x 90 beams, 2354x2464 canvases as copy-on-write tiles, maze scans (bench.py slam_entry)."]
+    t = glob.glob(os.path.join(base, "trace_sec", "*_results.db"))
+    if t:
+        cur = sqlite3.connect(t[0]).cursor()
+        big = cur.execute("select max(grid_x) from kernels where name like '%k_weights_S2%'").fetchone()[0]
+        w = cur.execute("select min(start), max(end), count(*) from kernels where name like '%k_weights_S2%' and grid_x=?", (big,)).fetchone()
+        lines.append(f"\n## kernel trace: the {w[2]} launches of k_weights_S2 with grid {big} threads and the tile kernels around them")
+        lines.append("%-84s %8s %12s %12s %12s" % ("kernel", "launches", "avg_ns", "min_ns", "max_ns"))
+        rows = cur.execute("select name, count(*), avg(end-start), min(end-start), max(end-start) from kernels where start>=? and end<=? "
+                           "and (name like '%k_weights_S2%' or name like '%k_tile_%' or name like '%k_tab_gather%' or name like '%k_set_sectors%') "
+                           "and (name not like '%k_weights_S2%' or grid_x=?) group by name order by 3 desc", (w[0] - 40_000_000, w[1] + 5_000_000, big)).fetchall()
+        for n, c, a, mn, mx in rows:
+            lines.append("%-84s %8d %12.0f %12d %12d" % (n[:84], c, a, mn, mx))
+    lines.append("\n## counters of k_weights_S2<true> per launch (largest grid only), separate passes")
+    waves = None
+    vals = {}
+    for sub in ("pmc_sq", "pmc_fetch", "pmc_l2", "pmc_grbm"):
+        for d in glob.glob(os.path.join(base, sub, "*_results.db")):
+            cur = sqlite3.connect(d).cursor()
+            big = cur.execute("select max(grid_size) from counters_collection where kernel_name like '%k_weights_S2%'").fetchone()[0]
+            for c, n, a in cur.execute("select counter_name, count(*), avg(value) from counters_collection where kernel_name like '%k_weights_S2%' "
+                                       "and grid_size=? group by counter_name order by counter_name", (big,)).fetchall():
+                lines.append("%-28s launches %4d  avg per launch %18.1f" % (c, n, a))
+                vals[c] = a
+    if "SQ_WAVES" in vals and "SQ_INSTS_VALU" in vals:
+        rays = vals["SQ_WAVES"] * 90.0
+        lines.append("   -> %.0f VALU and %.0f SALU wavefront instructions per ray (%.2f M rays per launch); round 1's k_weights_S_wave: 870 VALU"
+                     % (vals["SQ_INSTS_VALU"] / rays, vals.get("SQ_INSTS_SALU", 0.0) / rays, rays / 1e6))
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        lines.append("   -> HBM traffic per launch: %.2f GB read (FETCH_SIZE KB doubled for gfx950) + %.2f GB written"
+                     % (2 * vals["FETCH_SIZE"] * 1024 / 1e9, vals["WRITE_SIZE"] * 1024 / 1e9))
+    text = "\n".join(lines) + "\n"
+    open(os.path.join("profiles", f"rocprof_{tag}_slam.txt"), "w").write(text)
+    return text
 
 
 def pmc_stats(db):
@@ -110,9 +157,9 @@ def main(tag):
         name = os.path.basename(os.path.dirname(d))
         lines.append(f"\n## {name}")
         try:
-            lines.append(kernel_stats(d) if name == "trace" else pmc_stats(d))
+            lines.append(kernel_stats(d) if name.startswith("trace") else pmc_stats(d))
             if name == "trace":
-                lines.append("\n## timed region of the trace run (bench.py defaults: 5 warm-up + 20 timed steps)")
+                lines.append("\n## timed region of the trace run (bench.py defaults: 5 warm-up + 20 timed steps, then 20 steps bracketed by events)")
                 lines.append(timed_region(d))
         except Exception as e:  # noqa: BLE001
             lines.append(f"(could not read: {e})")
@@ -120,6 +167,7 @@ def main(tag):
     open(os.path.join("profiles", f"rocprof_{tag}.txt"), "w").write(text)
     print(text)
     print(weights_traffic(base))
+    print(slam_summary(base, tag))
 
 
 if __name__ == "__main__":
