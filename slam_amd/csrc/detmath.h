@@ -30,6 +30,23 @@ DM_HD double dm_sqrt(double x) { return __builtin_sqrt(x); }  // IEEE correctly 
 DM_HD double dm_fabs(double x) { return __builtin_fabs(x); }
 DM_HD uint32_t dm_hi(double x) { return (uint32_t)(dm_bits(x) >> 32); }
 
+// DM_KC(bits, dep): the constant with these bits.  On the device it is materialised where it is used (two 32-bit moves
+// that formally depend on `dep`, a value of the surrounding computation) instead of being hoisted out of every loop into a
+// register pair for the whole kernel: the polynomial constants of this header otherwise occupy 32 vector registers of
+// the ray kernels, which costs them a wavefront per SIMD.  Same value on both sides.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DM_NO_REMAT)
+template <uint64_t B>
+__device__ static inline double dm_kc(double dep)
+{
+    uint32_t lo, hi;
+    asm("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(lo), "=&v"(hi) : "n"((uint32_t)(B & 0xffffffffull)), "n"((uint32_t)(B >> 32)), "v"(dep));
+    return dm_from_bits(((uint64_t)hi << 32) | lo);
+}
+#define DM_KC(bits, dep) dm_kc<bits>(dep)
+#else
+#define DM_KC(bits, dep) dm_from_bits(bits)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // x * 2^n, exact except at the subnormal edge (same operation sequence on every platform).
 DM_HD double dm_scalbn(double x, int n)
@@ -133,12 +150,12 @@ DM_HD int dm_rem_pio2_abs(double t, double* y0, double* y1)
 // sin on [-pi/4, pi/4] of x + y (y = tail of the reduced argument).
 DM_HD double dm_ksin(double x, double y)
 {
-    const double S1 = dm_from_bits(0xBFC5555555555549ull);  // -1.66666666666666324348e-01
-    const double S2 = dm_from_bits(0x3F8111111110F8A6ull);  //  8.33333333332248946124e-03
-    const double S3 = dm_from_bits(0xBF2A01A019C161D5ull);  // -1.98412698298579493134e-04
-    const double S4 = dm_from_bits(0x3EC71DE357B1FE7Dull);  //  2.75573137070700676789e-06
-    const double S5 = dm_from_bits(0xBE5AE5E68A2B9CEBull);  // -2.50507602534068634195e-08
-    const double S6 = dm_from_bits(0x3DE5D93A5ACFD57Cull);  //  1.58969099521155010221e-10
+    const double S1 = DM_KC(0xBFC5555555555549ull, x);  // -1.66666666666666324348e-01
+    const double S2 = DM_KC(0x3F8111111110F8A6ull, x);  //  8.33333333332248946124e-03
+    const double S3 = DM_KC(0xBF2A01A019C161D5ull, x);  // -1.98412698298579493134e-04
+    const double S4 = DM_KC(0x3EC71DE357B1FE7Dull, x);  //  2.75573137070700676789e-06
+    const double S5 = DM_KC(0xBE5AE5E68A2B9CEBull, x);  // -2.50507602534068634195e-08
+    const double S6 = DM_KC(0x3DE5D93A5ACFD57Cull, x);  //  1.58969099521155010221e-10
     const double z = x * x;
     const double w = z * z;
     const double r = dm_fma(z, dm_fma(z, S4, S3), S2) + (z * w) * dm_fma(z, S6, S5);
@@ -149,12 +166,12 @@ DM_HD double dm_ksin(double x, double y)
 // cos on [-pi/4, pi/4] of x + y.
 DM_HD double dm_kcos(double x, double y)
 {
-    const double C1 = dm_from_bits(0x3FA555555555554Cull);  //  4.16666666666666019037e-02
-    const double C2 = dm_from_bits(0xBF56C16C16C15177ull);  // -1.38888888888741095749e-03
-    const double C3 = dm_from_bits(0x3EFA01A019CB1590ull);  //  2.48015872894767294178e-05
-    const double C4 = dm_from_bits(0xBE927E4F809C52ADull);  // -2.75573143513906633035e-07
-    const double C5 = dm_from_bits(0x3E21EE9EBDB4B1C4ull);  //  2.08757232129817482790e-09
-    const double C6 = dm_from_bits(0xBDA8FAE9BE8838D4ull);  // -1.13596475577881948265e-11
+    const double C1 = DM_KC(0x3FA555555555554Cull, x);  //  4.16666666666666019037e-02
+    const double C2 = DM_KC(0xBF56C16C16C15177ull, x);  // -1.38888888888741095749e-03
+    const double C3 = DM_KC(0x3EFA01A019CB1590ull, x);  //  2.48015872894767294178e-05
+    const double C4 = DM_KC(0xBE927E4F809C52ADull, x);  // -2.75573143513906633035e-07
+    const double C5 = DM_KC(0x3E21EE9EBDB4B1C4ull, x);  //  2.08757232129817482790e-09
+    const double C6 = DM_KC(0xBDA8FAE9BE8838D4ull, x);  // -1.13596475577881948265e-11
     const double z = x * x;
     const double w = z * z;
     const double r = z * dm_fma(z, dm_fma(z, C3, C2), C1) + (w * w) * dm_fma(z, dm_fma(z, C6, C5), C4);
@@ -199,13 +216,13 @@ DM_HD double dm_log(double x)
 {
     const double ln2_hi = dm_from_bits(0x3FE62E42FEE00000ull);  // 6.93147180369123816490e-01
     const double ln2_lo = dm_from_bits(0x3DEA39EF35793C76ull);  // 1.90821492927058770002e-10
-    const double Lg1 = dm_from_bits(0x3FE5555555555593ull);     // 6.666666666666735130e-01
-    const double Lg2 = dm_from_bits(0x3FD999999997FA04ull);     // 3.999999999940941908e-01
-    const double Lg3 = dm_from_bits(0x3FD2492494229359ull);     // 2.857142874366239149e-01
-    const double Lg4 = dm_from_bits(0x3FCC71C51D8E78AFull);     // 2.222219843214978396e-01
-    const double Lg5 = dm_from_bits(0x3FC7466496CB03DEull);     // 1.818357216161805012e-01
-    const double Lg6 = dm_from_bits(0x3FC39A09D078C69Full);     // 1.531383769920937332e-01
-    const double Lg7 = dm_from_bits(0x3FC2F112DF3E5244ull);     // 1.479819860511658591e-01
+    const double Lg1 = DM_KC(0x3FE5555555555593ull, x);     // 6.666666666666735130e-01
+    const double Lg2 = DM_KC(0x3FD999999997FA04ull, x);     // 3.999999999940941908e-01
+    const double Lg3 = DM_KC(0x3FD2492494229359ull, x);     // 2.857142874366239149e-01
+    const double Lg4 = DM_KC(0x3FCC71C51D8E78AFull, x);     // 2.222219843214978396e-01
+    const double Lg5 = DM_KC(0x3FC7466496CB03DEull, x);     // 1.818357216161805012e-01
+    const double Lg6 = DM_KC(0x3FC39A09D078C69Full, x);     // 1.531383769920937332e-01
+    const double Lg7 = DM_KC(0x3FC2F112DF3E5244ull, x);     // 1.479819860511658591e-01
 
     uint64_t u = dm_bits(x);
     uint32_t hx = (uint32_t)(u >> 32);
@@ -253,11 +270,11 @@ DM_HD double dm_exp(double x)
     const double ln2hi = dm_from_bits(0x3FE62E42FEE00000ull);
     const double ln2lo = dm_from_bits(0x3DEA39EF35793C76ull);
     const double invln2 = dm_from_bits(0x3FF71547652B82FEull);  // 1.44269504088896338700e+00
-    const double P1 = dm_from_bits(0x3FC555555555553Eull);      //  1.66666666666666019037e-01
-    const double P2 = dm_from_bits(0xBF66C16C16BEBD93ull);      // -2.77777777770155933842e-03
-    const double P3 = dm_from_bits(0x3F11566AAF25DE2Cull);      //  6.61375632143793436117e-05
-    const double P4 = dm_from_bits(0xBEBBBD41C5D26BF1ull);      // -1.65339022054652515390e-06
-    const double P5 = dm_from_bits(0x3E66376972BEA4D0ull);      //  4.13813679705723846039e-08
+    const double P1 = DM_KC(0x3FC555555555553Eull, x);      //  1.66666666666666019037e-01
+    const double P2 = DM_KC(0xBF66C16C16BEBD93ull, x);      // -2.77777777770155933842e-03
+    const double P3 = DM_KC(0x3F11566AAF25DE2Cull, x);      //  6.61375632143793436117e-05
+    const double P4 = DM_KC(0xBEBBBD41C5D26BF1ull, x);      // -1.65339022054652515390e-06
+    const double P5 = DM_KC(0x3E66376972BEA4D0ull, x);      //  4.13813679705723846039e-08
 
     uint32_t hx = dm_hi(x);
     const int sign = (int)(hx >> 31);

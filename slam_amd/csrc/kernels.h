@@ -136,6 +136,7 @@ struct WeightArgs
     int nseg, seg_beams;        // beams are cut into nseg segments of seg_beams
     const int32_t* order;       // optional: slot -> particle (pose-coherent order, see k_order_keys)
     int log_domain;             // SLAM_WEIGHT_LOG: store the sum of logs instead of its exp
+    int clamp_limit;            // localization hit search: stop a ray once it is beyond z + 4 sigma (ray_fast_L0's k_lim); off when hits are recorded
 };
 
 // K2a.  VARIANT 0: ray_fast_L on the clearance grid.  VARIANT 1: literal walk on the raw map
@@ -166,7 +167,8 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
             dm_sincos(theta, &s, &c);
             slam_ray_result r;
             if (VARIANT == 0)
-                ray_fast_L(a.grid, (unsigned)a.map_stride, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr);
+                ray_fast_L(a.grid, (unsigned)a.map_stride, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr,
+                           a.clamp_limit ? slam_sample_limit(a.z[b], a.stddev) : SLAM_NO_SAMPLE_LIMIT);
             else
                 ray_walk<false, true>(a.grid, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, nullptr, nullptr,
                                       a.max_iter, &r, &st);
@@ -200,7 +202,9 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
 // order, reproducing the sequential rounding of slam/mcl.cpp:69-74.
 // DIRECT (launches with one segment, i.e. enough particle blocks to fill the chip without cutting the beams): the lane
 // adds its particle's log-likelihoods itself, in beam order, and stores the weight: no slab, no k_sum_lw.
-template <int MIN_WAVES, bool DIRECT = false>
+// RECORD: also store every ray's hit position and cell (tests and tools; a variant of its own so that the production
+// kernels carry neither the branch nor the registers of the store addresses).
+template <int MIN_WAVES, bool DIRECT = false, bool RECORD = false>
 __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -227,6 +231,10 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     const int i0 = slam_f2i(((double)a.rows - sy) - 1.0), j0 = slam_f2i(sx);
     const bool inb0 = slam_in_bounds(a.rows, a.cols, i0, j0);
     const unsigned off0 = inb0 ? (unsigned)(slam_mul24(i0, a.cols + 4) + j0 + 2 * (a.cols + 4) + 2) : 0u;  // (frame corner: 0)
+    // what the exact-jump set-up needs of the start position, once per particle instead of once per ray
+    slam_axis_pre PX, PY;
+    slam_axis_prepare(&PX, sx);
+    slam_axis_prepare(&PY, sy);
     double* slab = DIRECT ? nullptr : a.lw + (size_t)pb * (size_t)a.B * 64 + lane;
     double acc = 0.0;
     const int b0 = seg * a.seg_beams;
@@ -234,18 +242,20 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     for (int b = b0; b < b1; ++b)
     {
         const double theta = pth + a.angles[b] + a.srot;
+        const double z = a.z[b];
         double s, c;
         dm_sincos(theta, &s, &c);
         slam_ray_result r;
         const unsigned plane_off = (unsigned)slam_octant(c, s) * (unsigned)a.map_stride;
-        ray_fast_L0(a.grid, plane_off, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, i0, j0, a.grid[off0 + plane_off],
-                    &r, nullptr);
-        const double lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
+        const int k_lim = a.clamp_limit ? slam_sample_limit(z, a.stddev) : SLAM_NO_SAMPLE_LIMIT;
+        ray_fast_L0(a.grid, plane_off, a.cols + 4, a.rows, a.cols, &PX, &PY, c, s, a.zmax2, a.k_safe, k_lim, i0, j0,
+                    a.grid[off0 + plane_off], &r, nullptr);
+        const double lw = slam_beam_logw(&r, sx, sy, z, a.zmax, a.stddev, a.norm, a.log_eps);
         if (DIRECT)
             acc += lw;  // slam/mcl.cpp:69-74
         else
             slab[(size_t)b * 64] = lw;
-        if (a.hit_xy)
+        if (RECORD)
         {
             const size_t o = (size_t)p * a.B + b;
             a.hit_xy[2 * o] = r.hx;

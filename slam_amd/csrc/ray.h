@@ -155,23 +155,48 @@ struct slam_axis
     int rem;     // adds that can still be replaced by fma(m, inc, v)
 };
 
-DM_HD void slam_axis_setup(slam_axis* a, double d)
+// The part of slam_axis_setup that depends on the coordinate alone.  Every beam of a particle starts from the same
+// sensor position, so the particle-lane kernel prepares the two axes once per particle and runs only
+// slam_axis_setup_pre per beam.
+struct slam_axis_pre
+{
+    double v;        // the coordinate
+    float nup, ndn;  // exact distance to the upper / lower edge of v's binade (in magnitude), rounded to float
+    int e;           // biased exponent of v
+    bool in_range;   // 4 <= |v| < 2^53
+    bool odd;        // v / ulp(v) is odd
+    bool neg;
+};
+
+DM_HD void slam_axis_prepare(slam_axis_pre* p, double v)
+{
+    const uint64_t b = dm_bits(v);
+    const int e = (int)((b >> 52) & 0x7ff);
+    const double av = dm_fabs(v);
+    const double lo = dm_from_bits((uint64_t)e << 52);
+    p->v = v;
+    p->nup = (float)((lo + lo) - av);  // exact differences
+    p->ndn = (float)(av - lo);
+    p->e = e;
+    p->in_range = (unsigned)(e - 0x401) <= (unsigned)(0x433 - 0x401);
+    p->odd = (b & 1) != 0;
+    p->neg = (b >> 63) != 0;
+}
+
+DM_HD void slam_axis_setup_pre(slam_axis* a, const slam_axis_pre* p, double d)
 {
     // straight-line code (every lane of a wavefront runs it once per ray): all quantities are
     // computed, the validity conditions select at the end
-    const uint64_t b = dm_bits(a->v);
-    const int e = (int)((b >> 52) & 0x7ff);
+    const int e = p->e;
     // C = 1.5 * 2^E: d + C lies in [2^E, 2^(E+1)) for |d| <= 1, so fl(d + C) is d rounded to the u grid
     const double C = dm_from_bits(((uint64_t)e << 52) | 0x0008000000000000ull);
     const double r = (d + C) - C;                                              // exact difference
     const double t = dm_fabs(d - r);                                           // exact residual, <= u/2
     const double half_ulp = dm_from_bits((uint64_t)(unsigned)(e - 53) << 52);  // u/2 = 2^(E-53)
-    const double av = dm_fabs(a->v);
-    const double lo = dm_from_bits((uint64_t)e << 52);
-    const bool grow = (r > 0.0) == ((b >> 63) == 0);
-    const double num = grow ? (lo + lo) - av : av - lo;   // exact distance to the binade edge
-    float q = (float)num * slam_rcpf((float)dm_fabs(r));  // |r| >= u >= 2^-50: no float underflow
-    q = q > 0.0f ? q : 0.0f;                              // (also NaN -> 0)
+    const bool grow = (r > 0.0) != p->neg;
+    const float num = grow ? p->nup : p->ndn;          // distance to the binade edge the coordinate moves towards
+    float q = num * slam_rcpf((float)dm_fabs(r));      // |r| >= u >= 2^-50: no float underflow
+    q = q > 0.0f ? q : 0.0f;                           // (also NaN -> 0)
     q = q < 1.0e6f ? q : 1.0e6f;
     // adds that land strictly inside the binade: ceil(num/|r|) - 1; the factor covers the float
     // rounding of q (relative 3e-7) and makes an exact integer quotient round down
@@ -179,10 +204,17 @@ DM_HD void slam_axis_setup(slam_axis* a, double d)
     if (r == 0.0) rem = 1 << 20;  // fl(v + d) == v for every add
     // |v| < 4 or |v| >= 2^53 (or inf/nan), |d| > 1, a tie from an odd v/u (one real add makes it
     // even): real adds only
-    const bool ok = ((unsigned)(e - 0x401) <= (unsigned)(0x433 - 0x401)) & (dm_fabs(d) <= 1.0) &
-                    !((t == half_ulp) & ((b & 1) != 0));
+    const bool ok = p->in_range & (dm_fabs(d) <= 1.0) & !((t == half_ulp) & p->odd);
+    a->v = p->v;
     a->inc = ok ? r : 0.0;
     a->rem = ok ? rem : 0;
+}
+
+DM_HD void slam_axis_setup(slam_axis* a, double d)
+{
+    slam_axis_pre p;
+    slam_axis_prepare(&p, a->v);
+    slam_axis_setup_pre(a, &p, d);
 }
 
 // One real add; re-derives inc/rem when the add left the binade or no constant increment was known.
@@ -259,9 +291,29 @@ DM_HD void slam_ray_origin(const uint8_t* Ep, unsigned plane_off, int pitch, int
 // Ep = the first plane, plane_off = byte offset of the ray's plane: every read is Ep[32-bit offset], which on the
 // device is one load with a scalar base and a 32-bit lane offset (the planes together stay below 4 GiB, see
 // slam_cone_planes_fit).
-DM_HD void ray_fast_L0(const uint8_t* Ep, unsigned plane_off, int pitch, int rows, int cols, double sx, double sy, double dx,
-                       double dy, double zmax2, int k_safe, int i0, int j0, unsigned e0, slam_ray_result* res, unsigned* reads)
+// PX, PY: the start position, prepared (slam_axis_prepare): the same for every beam of a particle.
+// k_lim: search limit in samples (>= k_safe: none).  The caller that only needs the beam likelihood passes
+// floor(z + 4 sigma) + 2: a hit at a later sample lies farther than z + 4 sigma from the origin (|(dx,dy)| = 1 to the
+// last bit and the accumulated rounding is below 1e-6 cells), where slam/util.cpp:14-19 clamps the density to 0
+// whatever the distance, and with k_lim < k_safe a ray without any hit is clamped as well (zmax - z > 4 sigma).  When
+// the limit ends the search the result is (-2, -2), cell -2, which slam_beam_logw maps to the clamped value; hits
+// within the limit and rays that leave the grid are reported as always.
+#define SLAM_NO_SAMPLE_LIMIT 0x7fffffff
+DM_HD void ray_fast_L0(const uint8_t* Ep, unsigned plane_off, int pitch, int rows, int cols, const slam_axis_pre* PX,
+                       const slam_axis_pre* PY, double dx, double dy, double zmax2, int k_safe, int k_lim, int i0, int j0,
+                       unsigned e0, slam_ray_result* res, unsigned* reads)
 {
+    const double sx = PX->v, sy = PY->v;
+    // the increments of the start position first: they do not depend on e0, whose load is still in flight on the device
+    slam_axis X, Y;
+    slam_axis_setup_pre(&X, PX, dx);
+    slam_axis_setup_pre(&Y, PY, dy);
+    const float adx = (float)dm_fabs(dx), ady = (float)dm_fabs(dy);
+    // samples to advance = 1 + floor((e-1) * 0.9999 / max(|dx|,|dy|)); the 1e-4 margin covers the
+    // float roundings (2^-23 relative on a value < 400), the single fused multiply-add makes
+    // host and device agree
+    const float sc = 0.9999f * slam_rcpf(adx > ady ? adx : ady);
+    const float sc1 = 1.0f - sc;
     res->hx = -1.0;
     res->hy = -1.0;
     res->hcell = -1;
@@ -272,7 +324,8 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, unsigned plane_off, int pitch, int row
     // (the literal loop then runs the whole range instead of only its last samples: a ray that starts just
     // outside a 2^20-cell side and heads inward is walked as far as the reference walks it)
     const bool far_out = !(dm_fabs(sx) < 1048576.0 && dm_fabs(sy) < 1048576.0);
-    int left = far_out ? 0 : k_safe;
+    const bool limited = !far_out && k_lim < k_safe;
+    int left = far_out ? 0 : (limited ? k_lim : k_safe);
     const int tail = far_out ? k_safe + 16 : 16;
     double x = sx, y = sy;
     // sample 0 (the start cell) is never tested (slam/raycast.cpp:153-157); its clearance still
@@ -305,25 +358,18 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, unsigned plane_off, int pitch, int row
                 return;
             }
         }
+        X.v = x;
+        Y.v = y;
+        slam_axis_setup(&X, dx);
+        slam_axis_setup(&Y, dy);
     }
     if (left > 0)
     {
         // (x, y) is an in-bounds sample with clearance e >= 1
-        slam_axis X = {x, 0.0, 0}, Y = {y, 0.0, 0};
-        slam_axis_setup(&X, dx);
-        slam_axis_setup(&Y, dy);
-        const float adx = (float)dm_fabs(dx), ady = (float)dm_fabs(dy);
-        // samples to advance = 1 + floor((e-1) * 0.9999 / max(|dx|,|dy|)); the 1e-4 margin covers the
-        // float roundings (2^-23 relative on a value < 400), the single fused multiply-add makes
-        // host and device agree
-        const float sc = 0.9999f * slam_rcpf(adx > ady ? adx : ady);
-        const float sc1 = 1.0f - sc;
         int budget = X.rem < Y.rem ? X.rem : Y.rem;  // samples the fma path may take before a re-synchronisation
         if (budget > left) budget = left;
         int budget0 = budget;
         double incx = X.inc, incy = Y.inc;
-        x = X.v;
-        y = Y.v;
         for (;;)
         {
             // advance m samples (any m' <= m would be legal too): one fma per axis ...
@@ -363,7 +409,7 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, unsigned plane_off, int pitch, int row
                 else
                 {
                     budget0 = 0;
-                    last = true;  // this sample is k_safe: test it, then continue with the literal loop
+                    last = true;  // this sample is k_safe (or the limit): test it, then continue with the literal loop
                 }
             }
             i = slam_f2i((rows_d - y) - 1.0);
@@ -385,6 +431,13 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, unsigned plane_off, int pitch, int row
             }
             return;  // otherwise slam/raycast.cpp:176
         }
+    }
+    if (limited)
+    {  // no hit within k_lim samples and still inside the grid: whatever follows is clamped
+        res->hx = -2.0;
+        res->hy = -2.0;
+        res->hcell = -2;
+        return;
     }
     // the literal loop from sample k_safe on (dedupe against the previous sample's cell, bounds,
     // hit, distance limit)
@@ -420,13 +473,23 @@ DM_HD int slam_octant(double dx, double dy)
 
 // planes: the 8 cone-clearance planes, plane_stride bytes apart (0: one Chebyshev-clearance plane serves every octant).
 DM_HD void ray_fast_L(const uint8_t* planes, unsigned plane_stride, int pitch, int rows, int cols, double sx, double sy, double dx,
-                      double dy, double zmax2, int k_safe, slam_ray_result* res, unsigned* reads)
+                      double dy, double zmax2, int k_safe, slam_ray_result* res, unsigned* reads, int k_lim = SLAM_NO_SAMPLE_LIMIT)
 {
     const unsigned plane_off = (unsigned)slam_octant(dx, dy) * plane_stride;
     int i0, j0;
     unsigned e0;
     slam_ray_origin(planes, plane_off, pitch, rows, cols, sx, sy, &i0, &j0, &e0, reads);
-    ray_fast_L0(planes, plane_off, pitch, rows, cols, sx, sy, dx, dy, zmax2, k_safe, i0, j0, e0, res, reads);
+    slam_axis_pre PX, PY;
+    slam_axis_prepare(&PX, sx);
+    slam_axis_prepare(&PY, sy);
+    ray_fast_L0(planes, plane_off, pitch, rows, cols, &PX, &PY, dx, dy, zmax2, k_safe, k_lim, i0, j0, e0, res, reads);
+}
+
+// The search limit of a beam of squared range z*z (see ray_fast_L0).
+DM_HD int slam_sample_limit(double z, double stddev)
+{
+    const double lim = z + 4.0 * stddev;
+    return lim < 1.0e9 ? slam_f2i(lim) + 2 : SLAM_NO_SAMPLE_LIMIT;  // (NaN: no limit)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -437,6 +500,7 @@ DM_HD double slam_beam_logw(const slam_ray_result* r, double sx, double sy, doub
                             double norm, double log_eps)
 {
     double xarg;
+    if (r->hx == -2.0) return log_eps;  // the search stopped at its limit: beyond the 4 sigma clamp (ray_fast_L0)
     if (r->hx == -1.0)
         xarg = z - zmax;
     else

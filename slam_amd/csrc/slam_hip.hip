@@ -228,6 +228,7 @@ struct Tuning
     int scan_fuse;   // SLAM_SCAN_FUSE: 1 = k_order_keys copies the new scan from its pinned slot (default), 0 = a copy of its own
     int s_kernel;    // SLAM_S_KERNEL: 0 = default (two-phase SLAM-mode kernel), 1 = legacy wave-per-ray kernel,
                      // 2 = two-phase kernel with every batch on its literal fallback (tests)
+    int clamp_limit; // SLAM_RAY_CLAMP_LIMIT: 1 = the localization hit search stops beyond z + 4 sigma (default), 0 = always to max_dist
 };
 const Tuning& tuning()
 {
@@ -236,7 +237,8 @@ const Tuning& tuning()
         return v ? atoi(v) : dflt;
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
-                             env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0)};
+                             env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
+                             env_int("SLAM_RAY_CLAMP_LIMIT", 1)};
     return t;
 }
 
@@ -416,6 +418,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.w = h->w;
     a.hit_xy = h->record_hits ? h->hit_xy : nullptr;
     a.hit_cell = h->record_hits ? h->hit_cell : nullptr;
+    a.clamp_limit = !h->record_hits && tuning().clamp_limit;  // recorded hits are the reference's, wherever they lie
     a.stats = h->stats;
     a.luts = h->luts;
     const int order_mode = tuning().order_mode;
@@ -593,10 +596,15 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             ext_started = true;
             if (direct)
             {
-                hipExtLaunchKernelGGL((slamk::k_rays_pl<5, true>), grid, dim3(256), 0, h->stream, ev_a, ext.b, 0, a);
+                if (a.hit_xy)
+                    hipExtLaunchKernelGGL((slamk::k_rays_pl<4, true, true>), grid, dim3(256), 0, h->stream, ev_a, ext.b, 0, a);
+                else
+                    hipExtLaunchKernelGGL((slamk::k_rays_pl<5, true>), grid, dim3(256), 0, h->stream, ev_a, ext.b, 0, a);
                 break;
             }
-            if (pl_waves >= 8)
+            if (a.hit_xy)
+                hipExtLaunchKernelGGL((slamk::k_rays_pl<4, false, true>), grid, dim3(256), 0, h->stream, ev_a, nullptr, 0, a);
+            else if (pl_waves >= 8)
                 hipExtLaunchKernelGGL(slamk::k_rays_pl<8>, grid, dim3(256), 0, h->stream, ev_a, nullptr, 0, a);
             else if (pl_waves >= 6)
                 hipExtLaunchKernelGGL(slamk::k_rays_pl<6>, grid, dim3(256), 0, h->stream, ev_a, nullptr, 0, a);

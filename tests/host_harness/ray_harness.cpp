@@ -125,3 +125,46 @@ HH_API void hh_fast_reads(const uint8_t* map, int rows, int cols, long n, const 
         reads_out[r] = (int)reads;
     }
 }
+
+// The sample limit of ray_fast_L0 (search only as far as z + 4 sigma): the beam log-likelihood must equal, bit for bit,
+// the one computed from the unlimited search.  Returns the number of differing rays; *stopped counts the rays the
+// limit ended, *reads_lim / *reads_full the clearance lookups of the two searches.
+HH_API long hh_limit_compare(const uint8_t* map, int rows, int cols, long n, const double* sx, const double* sy,
+                             const double* theta, const double* z, double zmax, double stddev, long* first_bad, long* stopped,
+                             unsigned long long* reads_lim, unsigned long long* reads_full)
+{
+    long bad = 0;
+    *first_bad = -1;
+    *stopped = 0;
+    *reads_lim = *reads_full = 0;
+    const double zmax2 = zmax * zmax;
+    int k_safe = (int)__builtin_floor(zmax) - 1;
+    if (k_safe < 0) k_safe = 0;
+    const std::vector<uint8_t> Ep = cone_planes(map, rows, cols);
+    const size_t stride = slam_cone_plane_stride(rows, cols);
+    const double norm = 1.0 / (stddev * __builtin_sqrt(2 * 3.14159265358979323846));
+    const double log_eps = dm_log(0.0 + 0.1);
+    for (long r = 0; r < n; ++r)
+    {
+        double s, c;
+        dm_sincos(theta[r], &s, &c);
+        slam_ray_result full, lim;
+        unsigned rf = 0, rl = 0;
+        ray_fast_L(Ep.data(), (unsigned)stride, cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &full, &rf);
+        ray_fast_L(Ep.data(), (unsigned)stride, cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &lim, &rl,
+                   slam_sample_limit(z[r], stddev));
+        *reads_full += rf;
+        *reads_lim += rl;
+        if (lim.hx == -2.0) ++*stopped;
+        const double zz = __builtin_sqrt(z[r] * z[r]);
+        const double a = slam_beam_logw(&full, sx[r], sy[r], zz, zmax, stddev, norm, log_eps);
+        const double b = slam_beam_logw(&lim, sx[r], sy[r], zz, zmax, stddev, norm, log_eps);
+        const bool same_hit = lim.hx == -2.0 || (!std::memcmp(&full.hx, &lim.hx, 8) && !std::memcmp(&full.hy, &lim.hy, 8) && full.hcell == lim.hcell);
+        if (std::memcmp(&a, &b, 8) || !same_hit)
+        {
+            if (!bad) *first_bad = r;
+            ++bad;
+        }
+    }
+    return bad;
+}

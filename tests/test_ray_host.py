@@ -109,6 +109,33 @@ def test_fast_hit_search_equals_literal_walk(hh, name):
     assert compare(hh, g, sx, sy, th, 500.0)[0] == 0
 
 
+@pytest.mark.parametrize("name", ["floor_plan", "maze"])
+def test_sample_limit_of_the_hit_search_keeps_the_beam_likelihood(hh, name):
+    """ray_fast_L0's k_lim: a search that stops beyond z + 4 sigma must give the same log-likelihood, bit for bit,
+    as the search to max_dist (slam/util.cpp:14-19 clamps the density to 0 beyond 4 sigma, slam/raycast.cpp:233-241)."""
+    rng = np.random.default_rng(21)
+    hh.hh_limit_compare.restype = ctypes.c_long
+    g = (orc.load_map(name) * 255).astype(np.uint8)
+    rows, cols = g.shape
+    total_stopped = 0
+    for n, zmax, sigma, spread in [(40000, 500.0, 5.0, 0), (20000, 500.0, 0.5, 30), (10000, 4000.0, 0.5, 0), (10000, 60.0, 20.0, 0),
+                                   (5000, 3.0, 0.1, 0)]:
+        sx, sy = rng.uniform(-spread, cols + spread, n), rng.uniform(-spread, rows + spread, n)
+        th = rng.uniform(-7, 7, n)
+        # ranges of every kind: short, near the limit, exactly max_dist, beyond it; some on whole cells
+        z = rng.uniform(0, zmax * 1.05, n)
+        z[::7] = zmax
+        z[1::7] = np.floor(z[1::7])
+        z[2::7] = np.maximum(zmax - 4 * sigma + rng.uniform(-3, 3, z[2::7].size), 0)
+        fb, st, rl, rf = ctypes.c_long(), ctypes.c_long(), ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        bad = hh.hh_limit_compare(ptr(g), rows, cols, ctypes.c_long(n), ptr(sx), ptr(sy), ptr(th), ptr(z), ctypes.c_double(zmax),
+                                  ctypes.c_double(sigma), ctypes.byref(fb), ctypes.byref(st), ctypes.byref(rl), ctypes.byref(rf))
+        assert bad == 0, (name, zmax, sigma, fb.value, sx[fb.value], sy[fb.value], th[fb.value], z[fb.value])
+        assert rl.value <= rf.value
+        total_stopped += st.value
+    assert total_stopped > 1000  # the limit does end searches
+
+
 def test_rays_from_beyond_two_to_the_twenty_are_walked_to_the_end(hh):
     """A grid side of 2^20 cells (the largest create() accepts): a ray that starts just outside it and heads inward
     lies in the coordinate range that takes the literal loop only; it must be walked as far as the reference walks
