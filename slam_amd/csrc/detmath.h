@@ -43,8 +43,12 @@ __device__ static inline double dm_kc(double dep)
     return dm_from_bits(((uint64_t)hi << 32) | lo);
 }
 #define DM_KC(bits, dep) dm_kc<bits>(dep)
+// DM_TIE(var, dep): no instruction; tells the compiler that var changes whenever dep does, so that values derived from
+// var are computed where they are used instead of being hoisted (and kept in registers) wherever dep is not invariant.
+#define DM_TIE(var, dep) asm("" : "+v"(var) : "v"(dep))
 #else
 #define DM_KC(bits, dep) dm_from_bits(bits)
+#define DM_TIE(var, dep) ((void)0)
 #endif
 
 // ---------------------------------------------------------------------------------------------

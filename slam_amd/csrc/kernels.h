@@ -122,6 +122,7 @@ struct WeightArgs
     int rows, cols, B;
     const double *angles, *z2, *z;  // per beam: angle, dist^2, sqrt(dist^2)
     double zmax2, zmax, stddev, norm, log_eps;
+    double clamp4;                  // 4 * stddev (slam/util.cpp:14-19)
     double sd, stheta, srot;        // scanner displacement (slam/mcl.cpp:80-86) and rotation
     int k_safe, max_iter;
     double* w;
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
             else
                 ray_walk<false, true>(a.grid, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, nullptr, nullptr,
                                       a.max_iter, &r, &st);
-            lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
+            lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps);
             if (a.hit_xy)
             {
                 const size_t o = (size_t)p * a.B + b;
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
         const int k_lim = a.clamp_limit ? slam_sample_limit(z, a.stddev) : SLAM_NO_SAMPLE_LIMIT;
         ray_fast_L0(a.grid, plane_off, a.cols + 4, a.rows, a.cols, &PX, &PY, c, s, a.zmax2, a.k_safe, k_lim, i0, j0,
                     a.grid[off0 + plane_off], &r, nullptr);
-        const double lw = slam_beam_logw(&r, sx, sy, z, a.zmax, a.stddev, a.norm, a.log_eps);
+        const double lw = slam_beam_logw(&r, sx, sy, z, a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps);
         if (DIRECT)
             acc += lw;  // slam/mcl.cpp:69-74
         else
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(64) k_weights_S(WeightArgs a)
         dm_sincos(theta, &s, &c);
         slam_ray_result r;
         ray_walk<true, true>(map, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, luts, luts + 256, a.max_iter, &r, &st);
-        acc += slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
+        acc += slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps);
         if (a.hit_xy)
         {
             const size_t o = (size_t)p * a.B + b;
@@ -707,7 +708,7 @@ __global__ void __launch_bounds__(256) k_weights_S_wave(WeightArgs a, TileArgs t
         double lw = 0.0;
         if (b < a.B)
         {
-            lw = slam_beam_logw(&mine, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
+            lw = slam_beam_logw(&mine, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps);
             if (a.hit_xy)
             {
                 const size_t o = (size_t)p * a.B + b;

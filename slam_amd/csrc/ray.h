@@ -177,6 +177,8 @@ DM_HD void slam_axis_prepare(slam_axis_pre* p, double v)
     p->v = v;
     p->nup = (float)((lo + lo) - av);  // exact differences
     p->ndn = (float)(av - lo);
+    DM_TIE(p->nup, v);  // (kept as the two floats: the compiler would otherwise keep the doubles and convert per ray)
+    DM_TIE(p->ndn, v);
     p->e = e;
     p->in_range = (unsigned)(e - 0x401) <= (unsigned)(0x433 - 0x401);
     p->odd = (b & 1) != 0;
@@ -187,7 +189,8 @@ DM_HD void slam_axis_setup_pre(slam_axis* a, const slam_axis_pre* p, double d)
 {
     // straight-line code (every lane of a wavefront runs it once per ray): all quantities are
     // computed, the validity conditions select at the end
-    const int e = p->e;
+    int e = p->e;
+    DM_TIE(e, d);  // C and half_ulp are rebuilt per ray (two instructions each) instead of living in four register pairs
     // C = 1.5 * 2^E: d + C lies in [2^E, 2^(E+1)) for |d| <= 1, so fl(d + C) is d rounded to the u grid
     const double C = dm_from_bits(((uint64_t)e << 52) | 0x0008000000000000ull);
     const double r = (d + C) - C;                                              // exact difference
@@ -496,7 +499,8 @@ DM_HD int slam_sample_limit(double z, double stddev)
 // Beam likelihood, slam/raycast.cpp:233-241 + slam/util.cpp:9-19, returning log(w) for the
 // accumulation of slam/mcl.cpp:73.  norm = 1/(stddev*sqrt(2 pi)), z = sqrt(z2), zmax = sqrt(zmax2).
 // log_eps = dm_log(0.0 + 0.1): the value of every beam whose error exceeds 4 sigma (pdf clamp).
-DM_HD double slam_beam_logw(const slam_ray_result* r, double sx, double sy, double z, double zmax, double stddev,
+// clamp = 4.0 * stddev, computed once by the caller (the host for the kernels: a scalar argument instead of a register pair).
+DM_HD double slam_beam_logw(const slam_ray_result* r, double sx, double sy, double z, double zmax, double stddev, double clamp,
                             double norm, double log_eps)
 {
     double xarg;
@@ -508,7 +512,7 @@ DM_HD double slam_beam_logw(const slam_ray_result* r, double sx, double sy, doub
         const double ex = r->hx - sx, ey = r->hy - sy;
         xarg = dm_sqrt(ex * ex + ey * ey) - z;
     }
-    if (dm_fabs(xarg) > 4.0 * stddev) return log_eps;
+    if (dm_fabs(xarg) > clamp) return log_eps;  // slam/util.cpp:14-19
     const double q = xarg / stddev;
     const double p = norm * dm_exp(-0.5 * (q * q));
     return dm_log(p + 0.1);

@@ -17,6 +17,7 @@
 #include "../../include/slam_hip.h"
 #include "clearance.h"
 #include "kernels.h"
+#include "sortk.h"
 
 #define SLAM_API extern "C" __attribute__((visibility("default")))
 
@@ -146,6 +147,7 @@ struct slam_mcl
     int32_t *oident = nullptr, *order = nullptr;
     void* osort_tmp = nullptr;
     size_t osort_tmp_bytes = 0;
+    void* ss_tmp = nullptr;  // scratch of the sample sort (sortk.h), shared by both sorts of a step
     int profile = 0;  // 0 off, 1 every group (an event pair per group), 2 the weighting group only, on the kernels' own dispatch timestamps where the path allows
     bool ext_timing = false;  // (set by do_weights while it times the pass through hipExtLaunchKernelGGL)
     std::vector<TimedSpan> spans;
@@ -228,6 +230,8 @@ struct Tuning
     int scan_fuse;   // SLAM_SCAN_FUSE: 1 = k_order_keys copies the new scan from its pinned slot (default), 0 = a copy of its own
     int s_kernel;    // SLAM_S_KERNEL: 0 = default (two-phase SLAM-mode kernel), 1 = legacy wave-per-ray kernel,
                      // 2 = two-phase kernel with every batch on its literal fallback (tests)
+    int sort_impl;   // SLAM_SORT_IMPL: bit 0 = weight sort, bit 1 = order sort by the sample sort of sortk.h (16k..256k particles); 0 = rocPRIM
+    int order_coarse;// SLAM_ORDER_COARSE: 1 = the pose-coherent order is sorted between the sample sort's buckets only, 0 = fully
     int clamp_limit; // SLAM_RAY_CLAMP_LIMIT: 1 = the localization hit search stops beyond z + 4 sigma (default), 0 = always to max_dist
 };
 const Tuning& tuning()
@@ -238,9 +242,12 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_RAY_CLAMP_LIMIT", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1)};
     return t;
 }
+
+// The sample sort serves the sizes at which rocPRIM's sort is a chain of launch-bound merge passes.
+bool use_sample_sort(const slam_mcl* h, int which) { return h->ss_tmp && (tuning().sort_impl & which) && h->n >= sortk::MIN_N && h->n <= sortk::MAX_N; }
 
 // SLAM_MAPS_TILED: new tables (src != nullptr: table p = old table src[p]), census of the tiles (who
 // owns what, exactly), free list of the unreferenced ones, allocation cursor restarted.
@@ -395,6 +402,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.zmax2 = max_dist * max_dist;      // slam/mcl.cpp:68
     a.zmax = std::sqrt(a.zmax2);        // slam/raycast.cpp:236
     a.stddev = stddev;
+    a.clamp4 = 4.0 * stddev;
     a.norm = 1.0 / (stddev * std::sqrt(2 * M_PI));  // slam/util.cpp:11
     a.log_eps = dm_log(0.0 + 0.1);                   // pdf clamped to 0 (slam/util.cpp:16) + EPSILON, slam/mcl.cpp:73
     a.lw = nullptr;
@@ -572,9 +580,14 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 int rc = scan_consumed(h);
                 if (rc) return rc;
             }
-            size_t bytes = h->osort_tmp_bytes;
-            HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, order_bits,
-                                             h->stream));
+            if (use_sample_sort(h, 2) && order_bits == 32)
+                sortk::sort_pairs(h->ss_tmp, h->okeys, h->oident, h->order, h->n, tuning().order_coarse != 0, h->stream);
+            else
+            {
+                size_t bytes = h->osort_tmp_bytes;
+                HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0,
+                                                 order_bits, h->stream));
+            }
             a.order = h->order;
         }
         for (int64_t pb0 = 0; pb0 < pblocks_all; pb0 += pb_per_launch)
@@ -757,9 +770,15 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
     if (h->prm.sort == SLAM_SORT_FULL)
     {
         slam_mcl::Span span(h, G_SORT);
-        size_t bytes = h->sort_tmp_bytes;
-        HIPCHK(rocprim::radix_sort_pairs_desc(h->sort_tmp, bytes, h->keys, h->keys2, h->slots, h->perm, (size_t)n, 0, 64,
-                                              h->stream));
+        // (weight descending, slot ascending): any stable sort gives this order
+        if (use_sample_sort(h, 1))
+            sortk::sort_pairs(h->ss_tmp, h->keys, h->slots, h->perm, n, false, h->stream);
+        else
+        {
+            size_t bytes = h->sort_tmp_bytes;
+            HIPCHK(rocprim::radix_sort_pairs_desc(h->sort_tmp, bytes, h->keys, h->keys2, h->slots, h->perm, (size_t)n, 0, 64,
+                                                  h->stream));
+        }
         perm = h->perm;
     }
     {
@@ -814,7 +833,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
                     h->grid,  h->clr,    h->maps, h->maps2,    h->luts,         h->scan_dev,
                     h->inj_normals, h->inj_uniforms, h->idx, h->perm, h->slots, h->src,   h->keys, h->keys2,
                     h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
-                    h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->wlin, h->wmax,
+                    h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->ss_tmp, h->wlin, h->wmax,
                     h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_who, h->tile_shared, h->tile_ctrl, h->tile_dense, h->tile_sector,
                     h->tile_wl_p, h->tile_wl_t, h->pack_stamp, h->pack_ctr, h->pack_slot, h->dev_bad};
     for (void* p : ptrs)
@@ -938,6 +957,12 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
             TRY(dev_alloc(&tmp, bytes ? bytes : 16));
             h->sort_tmp = tmp;
         }
+    }
+    if (!rc && n >= sortk::MIN_N && n <= sortk::MAX_N)
+    {
+        uint8_t* tmp = nullptr;
+        TRY(dev_alloc(&tmp, sortk::scratch_bytes(n)));
+        h->ss_tmp = tmp;
     }
     if (!rc)
     {

@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta,
         double lw = 0.0;
         if (b < a.B)
         {
-            lw = slam_beam_logw(&mine, sx, sy, a.z[b], a.zmax, a.stddev, a.norm, a.log_eps);
+            lw = slam_beam_logw(&mine, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps);
             if (a.hit_xy)
             {
                 const size_t o = (size_t)p * a.B + b;

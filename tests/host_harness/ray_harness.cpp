@@ -157,8 +157,8 @@ HH_API long hh_limit_compare(const uint8_t* map, int rows, int cols, long n, con
         *reads_lim += rl;
         if (lim.hx == -2.0) ++*stopped;
         const double zz = __builtin_sqrt(z[r] * z[r]);
-        const double a = slam_beam_logw(&full, sx[r], sy[r], zz, zmax, stddev, norm, log_eps);
-        const double b = slam_beam_logw(&lim, sx[r], sy[r], zz, zmax, stddev, norm, log_eps);
+        const double a = slam_beam_logw(&full, sx[r], sy[r], zz, zmax, stddev, 4.0 * stddev, norm, log_eps);
+        const double b = slam_beam_logw(&lim, sx[r], sy[r], zz, zmax, stddev, 4.0 * stddev, norm, log_eps);
         const bool same_hit = lim.hx == -2.0 || (!std::memcmp(&full.hx, &lim.hx, 8) && !std::memcmp(&full.hy, &lim.hy, 8) && full.hcell == lim.hcell);
         if (std::memcmp(&a, &b, 8) || !same_hit)
         {

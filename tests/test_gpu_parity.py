@@ -426,6 +426,40 @@ def test_resample_indices_bit_exact(sa, order, N):
     f.close()
 
 
+@pytest.mark.parametrize("N", [16384, 50001, 100000, 262144])
+def test_weight_sort_of_the_sample_sort_sizes(sa, N):
+    """slam/mcl.cpp:232-239 at the sizes served by the sample sort of sortk.h (16k..256k particles): the order must be
+    (weight descending, slot ascending) whatever the weights look like: heavy ties (few distinct weights, so that most
+    buckets' splitters are decided by the slot), one surviving particle (every key equal), already sorted and reversed
+    inputs, a tiny dynamic range, and one value that owns half of the array (its bucket does not fit LDS if the
+    samples were unlucky; here it must simply be right)."""
+    rng = np.random.default_rng(N)
+    cases = {
+        "generic": rng.uniform(0, 1, N) ** 8,
+        "three values": rng.choice([1e-300, 0.25, 0.5], N),
+        "one survivor": np.where(np.arange(N) == N // 3, 1.0, 0.0),
+        "ascending": np.linspace(1e-9, 1.0, N),
+        "descending": np.linspace(1.0, 1e-9, N),
+        "narrow": 1.0 + rng.integers(0, 50, N) * 2.0 ** -52,
+        "half equal": np.where(rng.uniform(size=N) < 0.5, 0.125, rng.uniform(0, 1, N)),
+    }
+    f = sa.Filter(N, 16, 16, noise=sa.capi.NOISE_INJECTED)
+    x = rng.uniform(0, 16, N)
+    for name, w in cases.items():
+        u = orc.reference_uniforms(N, tick=len(name))
+        f.set_poses(x, x, x)
+        f.set_weights(w)
+        f.set_noise(canonical_uniforms=u)
+        f.resample()
+        idx = f.last_indices()
+        keys = w[idx]
+        want = np.argsort(-keys, kind="stable")
+        perm = f.last_order()
+        assert np.array_equal(perm, want), name
+        assert_bits(f.weights(), keys[want], name)
+    f.close()
+
+
 def test_resample_all_zero_and_single_survivor(sa):
     for N in (9, 1000):
         f = sa.Filter(N, 16, 16, noise=sa.capi.NOISE_INJECTED)
