@@ -240,10 +240,14 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     double acc = 0.0;
     const int b0 = seg * a.seg_beams;
     const int b1 = (b0 + a.seg_beams) < a.B ? (b0 + a.seg_beams) : a.B;
+    // the scan entries are the same for every lane and are not written during the launch: read through the scalar cache
+    // (constant address space), which frees the vector memory pipeline and four registers per lane
+    typedef const double __attribute__((address_space(4))) * scan_ptr;
+    const scan_ptr angles_c = (scan_ptr)(uintptr_t)a.angles, z_c = (scan_ptr)(uintptr_t)a.z;
     for (int b = b0; b < b1; ++b)
     {
-        const double theta = pth + a.angles[b] + a.srot;
-        const double z = a.z[b];
+        const double theta = pth + angles_c[b] + a.srot;
+        const double z = z_c[b];
         double s, c;
         dm_sincos(theta, &s, &c);
         slam_ray_result r;
