@@ -9,7 +9,7 @@
 //                    workgroup, bucket counts per workgroup;
 //   3. k_ss_scan     one workgroup per bucket: exclusive scan of its counts over the workgroups of step 2, and its total;
 //   4. k_ss_scatter  every element goes to its bucket, in input order inside (bucket, workgroup): stable;
-//   5. k_ss_buckets  one workgroup per four buckets (about n/1024 elements each) ranks their elements by counting in LDS
+//   5. k_ss_buckets  one workgroup per two buckets (about n/1024 elements each) ranks their elements by counting in LDS
 //                    and writes the values out.  Step 5 can be left out ("coarse"): the result is then ordered between buckets only,
 //                    and in input order inside a bucket.
 // Networks of compare-exchanges in LDS were measured first (256 buckets of ~400 elements, bitonic): 670 cycles per stage,
@@ -26,7 +26,7 @@
 namespace sortk
 {
 constexpr int BUCKETS = 1024;
-constexpr int SAMPLES = 4096;
+constexpr int SAMPLES = 4096;  // (2^12: k_ss_sample shifts by 12)
 constexpr int ITEMS = 1024;     // elements per workgroup in steps 2 and 4 (256 threads x 4)
 constexpr int64_t MIN_N = 16384, MAX_N = 262144;
 
@@ -103,8 +103,10 @@ __global__ void __launch_bounds__(256) k_ss_sample(const K* keys, int n, Scratch
     {
         // (straight-line: the 16 loads of a thread are in flight together)
         const int q = u * 256 + t;
-        const uint32_t width = (uint32_t)n / SAMPLES;  // >= 4; the last n % 4096 elements are in no stratum, which costs nothing
-        const int32_t pos = (int32_t)(q * width + __umulhi(hash32((uint32_t)q * 2654435761u + (uint32_t)n), width));
+        // stratum q = [q n / 4096, (q + 1) n / 4096): together they cover every position (an unsampled remainder at the end
+        // would fall into ONE bucket whenever most keys are equal, e.g. the children of a dominant particle)
+        const uint32_t lo = (uint32_t)(((uint64_t)q * (uint32_t)n) >> 12), hi = (uint32_t)(((uint64_t)(q + 1) * (uint32_t)n) >> 12);
+        const int32_t pos = (int32_t)(lo + __umulhi(hash32((uint32_t)q * 2654435761u + (uint32_t)n), hi - lo));
         sk[q] = to_sort_key(keys[pos]);
         sp[q] = pos;
     }
@@ -320,11 +322,12 @@ __device__ __forceinline__ int count_less(const uint64_t* k, const int32_t* p, i
     return r;
 }
 
-// Four consecutive buckets per workgroup: their elements are one contiguous range, loaded into LDS once; every thread
-// ranks its elements inside their own bucket.  (One wavefront per bucket was the first form: the largest of 1024 buckets
-// holds 3-4 times the mean, and its wavefront set the time.)
-constexpr int GROUP = 4;
-constexpr int GROUP_CAP = 4096;  // elements of one group ranked in LDS (48 KB)
+// Two consecutive buckets per workgroup: their elements are one contiguous range, loaded into LDS once; every thread
+// ranks its element inside its own bucket (about 200 elements per workgroup: one per thread; the largest of 1024 buckets
+// holds 3-4 times the mean and sets the time: one wavefront per bucket took 58 us, this form 26 us, of which 5 us are
+// everything but the comparisons: 64-bit integer compares and the mask logic of the composite order are what is left).
+constexpr int GROUP = 2;
+constexpr int GROUP_CAP = 2048;  // elements of one group ranked in LDS (24 KB)
 template <typename V>
 __global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V* out_vals)
 {
