@@ -123,6 +123,7 @@ struct WeightArgs
     const double *angles, *z2, *z;  // per beam: angle, dist^2, sqrt(dist^2)
     double zmax2, zmax, stddev, norm, log_eps;
     double clamp4;                  // 4 * stddev (slam/util.cpp:14-19)
+    double inv_stddev;              // RN(1 / stddev), or 0: divide (slam_beam_logw)
     double sd, stheta, srot;        // scanner displacement (slam/mcl.cpp:80-86) and rotation
     int k_safe, max_iter;
     double* w;
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
         const int k_lim = a.clamp_limit ? slam_sample_limit(z, a.stddev) : SLAM_NO_SAMPLE_LIMIT;
         ray_fast_L0(a.grid, plane_off, a.cols + 4, a.rows, a.cols, &PX, &PY, c, s, a.zmax2, a.k_safe, k_lim, i0, j0,
                     a.grid[off0 + plane_off], &r, nullptr);
-        const double lw = slam_beam_logw(&r, sx, sy, z, a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps);
+        const double lw = slam_beam_logw(&r, sx, sy, z, a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps, a.inv_stddev);
         if (DIRECT)
             acc += lw;  // slam/mcl.cpp:69-74
         else

@@ -500,8 +500,14 @@ DM_HD int slam_sample_limit(double z, double stddev)
 // accumulation of slam/mcl.cpp:73.  norm = 1/(stddev*sqrt(2 pi)), z = sqrt(z2), zmax = sqrt(zmax2).
 // log_eps = dm_log(0.0 + 0.1): the value of every beam whose error exceeds 4 sigma (pdf clamp).
 // clamp = 4.0 * stddev, computed once by the caller (the host for the kernels: a scalar argument instead of a register pair).
+// inv_stddev: 0, or RN(1 / stddev) for a stddev in [1e-100, 1e100]: the quotient xarg / stddev of slam/util.cpp:11 is then
+// formed from the reciprocal with two correction steps (5 multiply-adds instead of the 12-instruction division sequence).
+// The result is the correctly rounded quotient, i.e. the same bits: q0 = RN(a y) is within 2 ulp of a/b (y = RN(1/b));
+// q1 = RN(q0 + RN(a - b q0) y) is within 1 ulp (faithful), for which r1 = a - b q1 is exact and RN(q1 + r1 y) = RN(a/b)
+// (Markstein's theorem, which needs exactly: y the correctly rounded reciprocal, q1 faithful, no over/underflow:
+// |a| is 0 or at least 1e-17 here and |a / b| <= 4).
 DM_HD double slam_beam_logw(const slam_ray_result* r, double sx, double sy, double z, double zmax, double stddev, double clamp,
-                            double norm, double log_eps)
+                            double norm, double log_eps, double inv_stddev = 0.0)
 {
     double xarg;
     if (r->hx == -2.0) return log_eps;  // the search stopped at its limit: beyond the 4 sigma clamp (ray_fast_L0)
@@ -513,7 +519,15 @@ DM_HD double slam_beam_logw(const slam_ray_result* r, double sx, double sy, doub
         xarg = dm_sqrt(ex * ex + ey * ey) - z;
     }
     if (dm_fabs(xarg) > clamp) return log_eps;  // slam/util.cpp:14-19
-    const double q = xarg / stddev;
+    double q;
+    if (inv_stddev != 0.0)
+    {
+        const double q0 = xarg * inv_stddev;
+        const double q1 = dm_fma(dm_fma(-q0, stddev, xarg), inv_stddev, q0);
+        q = dm_fma(dm_fma(-q1, stddev, xarg), inv_stddev, q1);
+    }
+    else
+        q = xarg / stddev;
     const double p = norm * dm_exp(-0.5 * (q * q));
     return dm_log(p + 0.1);
 }

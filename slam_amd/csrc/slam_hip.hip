@@ -232,6 +232,7 @@ struct Tuning
                      // 2 = two-phase kernel with every batch on its literal fallback (tests)
     int sort_impl;   // SLAM_SORT_IMPL: bit 0 = weight sort, bit 1 = order sort by the sample sort of sortk.h (16k..256k particles); 0 = rocPRIM
     int order_coarse;// SLAM_ORDER_COARSE: 1 = the pose-coherent order is sorted between the sample sort's buckets only, 0 = fully
+    int fast_div;    // SLAM_FAST_DIV: 1 = the particle-lane kernel forms xarg / stddev from the reciprocal (same bits), 0 = divides
     int clamp_limit; // SLAM_RAY_CLAMP_LIMIT: 1 = the localization hit search stops beyond z + 4 sigma (default), 0 = always to max_dist
 };
 const Tuning& tuning()
@@ -242,7 +243,7 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1)};
     return t;
 }
 
@@ -403,6 +404,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.zmax = std::sqrt(a.zmax2);        // slam/raycast.cpp:236
     a.stddev = stddev;
     a.clamp4 = 4.0 * stddev;
+    a.inv_stddev = (stddev >= 1.0e-100 && stddev <= 1.0e100 && tuning().fast_div) ? 1.0 / stddev : 0.0;
     a.norm = 1.0 / (stddev * std::sqrt(2 * M_PI));  // slam/util.cpp:11
     a.log_eps = dm_log(0.0 + 0.1);                   // pdf clamped to 0 (slam/util.cpp:16) + EPSILON, slam/mcl.cpp:73
     a.lw = nullptr;

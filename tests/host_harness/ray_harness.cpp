@@ -168,3 +168,20 @@ HH_API long hh_limit_compare(const uint8_t* map, int rows, int cols, long n, con
     }
     return bad;
 }
+
+// The quotient xarg / stddev of slam_beam_logw formed from the reciprocal (two correction steps) against the division:
+// returns the number of pairs whose results differ in any bit.
+HH_API long hh_fast_div_check(long n, const double* a, const double* b)
+{
+    long bad = 0;
+    for (long i = 0; i < n; ++i)
+    {
+        const double y = 1.0 / b[i];
+        const double q0 = a[i] * y;
+        const double q1 = dm_fma(dm_fma(-q0, b[i], a[i]), y, q0);
+        const double q = dm_fma(dm_fma(-q1, b[i], a[i]), y, q1);
+        const double want = a[i] / b[i];
+        if (std::memcmp(&q, &want, 8)) ++bad;
+    }
+    return bad;
+}

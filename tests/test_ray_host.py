@@ -136,6 +136,24 @@ def test_sample_limit_of_the_hit_search_keeps_the_beam_likelihood(hh, name):
     assert total_stopped > 1000  # the limit does end searches
 
 
+def test_quotient_from_the_reciprocal_is_the_correctly_rounded_quotient(hh):
+    """slam_beam_logw forms xarg / stddev (slam/util.cpp:11) from RN(1 / stddev) with two correction steps in the
+    particle-lane kernel; the result must be the division's, bit for bit: random operands in the range the kernel
+    uses (|xarg| <= 4 stddev), operands one ulp around exact quotients, denominators with all-ones significands
+    (where the reciprocal is hardest) and the extremes of the accepted stddev range."""
+    rng = np.random.default_rng(31)
+    hh.hh_fast_div_check.restype = ctypes.c_long
+    n = 2_000_000
+    b = np.concatenate([rng.uniform(0.01, 50.0, n // 2), 10.0 ** rng.uniform(-100, 100, n // 4),
+                        np.nextafter(2.0 ** rng.integers(-300, 300, n // 4).astype(float), 0.0)])
+    a = rng.uniform(-4, 4, n) * b
+    q = np.round(rng.uniform(-4, 4, n // 4) * 2.0 ** 30) / 2.0 ** 30   # short quotients: a = q b is nearly exact
+    a[:n // 4] = np.nextafter(q * b[:n // 4], rng.choice([-np.inf, np.inf], n // 4))
+    a[n // 4:n // 4 + 1000] = 0.0
+    a[n // 4 + 1000:n // 4 + 2000] = rng.choice([-1.0, 1.0], 1000) * 2.2e-16
+    assert hh.hh_fast_div_check(ctypes.c_long(n), ptr(a), ptr(b)) == 0
+
+
 def test_rays_from_beyond_two_to_the_twenty_are_walked_to_the_end(hh):
     """A grid side of 2^20 cells (the largest create() accepts): a ray that starts just outside it and heads inward
     lies in the coordinate range that takes the literal loop only; it must be walked as far as the reference walks
