@@ -51,6 +51,17 @@ __device__ static inline double dm_kc(double dep)
 #define DM_TIE(var, dep) ((void)0)
 #endif
 
+// DM_ANY(cond): cond on the host; on the device "cond holds in some lane of the wavefront", a scalar branch the compiler
+// cannot turn into straight-line selects.  For rare, expensive cases: the body must still test cond per lane.
+// DM_COLD(): first statement of such a body; keeps the compiler from executing the body speculatively anyway.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DM_ANY(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
+#define DM_COLD() asm volatile("; rare path")
+#else
+#define DM_ANY(cond) (cond)
+#define DM_COLD() ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // x * 2^n, exact except at the subnormal edge (same operation sequence on every platform).
 DM_HD double dm_scalbn(double x, int n)
@@ -138,13 +149,19 @@ DM_HD int dm_rem_pio2_abs(double t, double* y0, double* y1)
     double a = r - w;
     const int j = (int)((dm_bits(t) >> 52) & 0x7ff);
     const int i = j - (int)((dm_bits(a) >> 52) & 0x7ff);
-    if (i > 49)
-    {  // heavy cancellation: third piece, 151 bits of pi/2
-        t2 = r;
-        w = fn * pio2_3;
-        r = t2 - w;
-        w = fn * pio2_3t - ((t2 - r) - w);
-        a = r - w;
+    if (DM_ANY(i > 49))
+    {  // heavy cancellation (the argument within 2^-49 of a multiple of pi/2): third piece, 151 bits of pi/2
+        DM_COLD();
+        const double t3 = r;
+        const double w3 = fn * pio2_3;
+        const double r3 = t3 - w3;
+        const double w4 = fn * pio2_3t - ((t3 - r3) - w3);
+        if (i > 49)
+        {
+            r = r3;
+            w = w4;
+            a = r3 - w4;
+        }
     }
     *y0 = a;
     *y1 = (r - a) - w;
