@@ -461,7 +461,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "note": "achieved/frac are ALGORITHMIC, reference-equivalent bytes (cells the reference's walk would read, SURVEY.md §8d) "
                         "over the kernel time; the clearance search reads far fewer bytes and the binding limit is VALU issue (DESIGN.md §6)",
-                "kernel": "weighting pass = k_order_keys + radix sort + k_rays_pl + k_sum_lw (raycast + beam likelihood)", "kernel_avg_ms": k_avg_ms,
+                "kernel": "weighting pass = k_order_keys + pose-coherent order (sample sort, 4 launches) + k_rays_pl + k_sum_lw (raycast + beam likelihood)", "kernel_avg_ms": k_avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes, "cells_per_ray_reference_walk": sbar,
                 "kernel_particle_beams_per_s": n_loc * B / (k_avg_ms * 1e-3),
             },
