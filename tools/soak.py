@@ -35,10 +35,17 @@ while time.time() - t0 < budget:
         f = sa.Filter(N, rows, cols, raycaster=rc, sort=capi.SORT_NONE, weight_domain=capi.WEIGHT_LOG)
         f.set_map(g); f.set_poses(x, y, th); f.record_hits(True)
         f.update_weights(ang, dist, sd, zmax, off)
-        res[shape] = (f.weights(), *f.hits()); f.close()
+        res[shape] = (f.weights(), *f.hits())
+        if shape != "walk":
+            # without recorded hits the hit search stops beyond z + 4 sigma (ray_fast_L0's k_lim): same weights
+            f.record_hits(False)
+            f.update_weights(ang, dist, sd, zmax, off)
+            res[shape + "/limit"] = f.weights()
+        f.close()
     for shape in ("beam", "plane"):
         ok = np.array_equal(res[shape][2], res["walk"][2]) and np.array_equal(res[shape][1].view(np.uint64), res["walk"][1].view(np.uint64)) \
             and np.array_equal(res[shape][0].view(np.uint64), res["walk"][0].view(np.uint64))
+        ok = ok and np.array_equal(res[shape + "/limit"].view(np.uint64), res["walk"][0].view(np.uint64))
         if not ok:
             print("MISMATCH", shape, name, g.shape, N, B, zmax, off, cx, cy, spread, flush=True)
             np.savez(os.path.join(ROOT, "gpurun_out", "soak_fail.npz"), g=g, x=x, y=y, th=th, ang=ang, dist=dist, zmax=zmax, off=off, sd=sd)
