@@ -232,6 +232,7 @@ struct Tuning
                      // 2 = two-phase kernel with every batch on its literal fallback (tests)
     int sort_impl;   // SLAM_SORT_IMPL: bit 0 = weight sort, bit 1 = order sort by the sample sort of sortk.h (16k..256k particles); 0 = rocPRIM
     int order_coarse;// SLAM_ORDER_COARSE: 1 = the pose-coherent order is sorted between the sample sort's buckets only, 0 = fully
+    int ss_lds_cap;  // SLAM_SS_LDS_CAP: largest group of buckets the sample sort ranks in LDS (tests force the path from memory)
     int fast_div;    // SLAM_FAST_DIV: 1 = the particle-lane kernel forms xarg / stddev from the reciprocal (same bits), 0 = divides
     int clamp_limit; // SLAM_RAY_CLAMP_LIMIT: 1 = the localization hit search stops beyond z + 4 sigma (default), 0 = always to max_dist
 };
@@ -243,7 +244,7 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1)};
     return t;
 }
 
@@ -774,7 +775,7 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
         slam_mcl::Span span(h, G_SORT);
         // (weight descending, slot ascending): any stable sort gives this order
         if (use_sample_sort(h, 1))
-            sortk::sort_pairs(h->ss_tmp, h->keys, h->slots, h->perm, n, false, h->stream);
+            sortk::sort_pairs(h->ss_tmp, h->keys, h->slots, h->perm, n, false, h->stream, tuning().ss_lds_cap);
         else
         {
             size_t bytes = h->sort_tmp_bytes;

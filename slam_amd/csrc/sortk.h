@@ -329,7 +329,7 @@ __device__ __forceinline__ int count_less(const uint64_t* k, const int32_t* p, i
 constexpr int GROUP = 2;
 constexpr int GROUP_CAP = 2048;  // elements of one group ranked in LDS (24 KB)
 template <typename V>
-__global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V* out_vals)
+__global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V* out_vals, int lds_cap /* <= GROUP_CAP */)
 {
     __shared__ uint64_t sk[GROUP_CAP];
     __shared__ int32_t sp[GROUP_CAP];
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V*
     const int b0 = blockIdx.x * GROUP;
     const int first = off[b0], total = off[b0 + GROUP] - first;
     if (total <= 0) return;
-    const bool in_lds = total <= GROUP_CAP;
+    const bool in_lds = total <= lds_cap;
     if (in_lds)
     {
         for (int e = t; e < total; e += 256)
@@ -378,7 +378,8 @@ __global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V*
 
 // Enqueues the sort on `stream`.  scratch: scratch_bytes(n) bytes, 256-byte aligned.  coarse: steps 1-4 only.
 template <typename K, typename V>
-__host__ inline void sort_pairs(void* scratch, const K* keys, const V* vals, V* out_vals, int64_t n, bool coarse, hipStream_t stream)
+__host__ inline void sort_pairs(void* scratch, const K* keys, const V* vals, V* out_vals, int64_t n, bool coarse, hipStream_t stream,
+                                int lds_cap = GROUP_CAP /* tests: a smaller value sends groups of buckets to the ranking from memory */)
 {
     const Scratch s = carve(scratch, n);
     const int nblocks = (int)((n + ITEMS - 1) / ITEMS);
@@ -390,7 +391,8 @@ __host__ inline void sort_pairs(void* scratch, const K* keys, const V* vals, V* 
     else
     {
         hipLaunchKernelGGL((k_ss_scatter<K, V, false>), dim3(nblocks), dim3(256), 0, stream, keys, vals, (int)n, nblocks, s, out_vals);
-        hipLaunchKernelGGL((k_ss_buckets<V>), dim3(BUCKETS / GROUP), dim3(256), 0, stream, vals, s, out_vals);
+        hipLaunchKernelGGL((k_ss_buckets<V>), dim3(BUCKETS / GROUP), dim3(256), 0, stream, vals, s, out_vals,
+                           lds_cap < GROUP_CAP ? lds_cap : GROUP_CAP);
     }
 }
 }  // namespace sortk

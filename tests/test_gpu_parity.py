@@ -460,6 +460,42 @@ def test_weight_sort_of_the_sample_sort_sizes(sa, N):
     f.close()
 
 
+def test_sample_sort_equals_rocprim_and_its_path_from_memory(sa, tmp_path):
+    """The same resample + sort in three child processes: sample sort (default), sample sort with every group of buckets
+    ranked from memory instead of LDS (SLAM_SS_LDS_CAP=16: the path a skewed sample would take), rocPRIM
+    (SLAM_SORT_IMPL=0).  All three must give the same permutation and the same sorted state."""
+    import subprocess
+    import sys
+
+    code = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import _oracle as orc, slam_amd as sa
+out = {}
+for N in (20000, 100000):
+    rng = np.random.default_rng(N)
+    f = sa.Filter(N, 16, 16, noise=sa.capi.NOISE_INJECTED)
+    for name, w in (("generic", rng.uniform(0, 1, N) ** 8), ("ties", rng.choice([1e-300, 0.25, 0.5], N))):
+        x = rng.uniform(0, 16, N)
+        f.set_poses(x, x, x); f.set_weights(w); f.set_noise(canonical_uniforms=orc.reference_uniforms(N, tick=7)); f.resample()
+        out[f"{N}_{name}_perm"] = f.last_order(); out[f"{N}_{name}_w"] = f.weights()
+    f.close()
+np.savez(sys.argv[3], **out)
+"""
+    root = os.path.dirname(HERE)
+    res = {}
+    for tag, env in (("sample", {}), ("memory", {"SLAM_SS_LDS_CAP": "16"}), ("rocprim", {"SLAM_SORT_IMPL": "0"})):
+        path = str(tmp_path / f"{tag}.npz")
+        subprocess.run([sys.executable, "-c", code, root, HERE, path], check=True, env=dict(os.environ, **env), timeout=300)
+        res[tag] = np.load(path)
+    for k in res["rocprim"].files:
+        for tag in ("sample", "memory"):
+            if k.endswith("_w"):
+                assert_bits(res[tag][k], res["rocprim"][k], f"{tag} {k}")
+            else:
+                assert np.array_equal(res[tag][k], res["rocprim"][k]), f"{tag} {k}"
+
+
 def test_resample_all_zero_and_single_survivor(sa):
     for N in (9, 1000):
         f = sa.Filter(N, 16, 16, noise=sa.capi.NOISE_INJECTED)
