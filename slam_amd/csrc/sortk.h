@@ -301,24 +301,28 @@ __global__ void __launch_bounds__(256) k_ss_scatter(const K* keys, const V* vals
     }
 }
 
-// Number of entries of (k[lo..hi), p[lo..hi)) below (key, pos); eight independent comparisons per trip.
-__device__ __forceinline__ int count_less(const uint64_t* k, const int32_t* p, int lo, int hi, uint64_t key, int32_t pos)
+// Rank of element e of a bucket [lo, hi) = number of its entries below (key, position of e).  The scatter is stable, so
+// inside a bucket the positions ascend with the index: an entry u with the same key is below e exactly when u < e, and
+// "below" becomes ONE 64-bit comparison per entry, k[u] < key + (u < e), with no position read (key + 1 cannot wrap: the
+// all-ones sort key is a NaN weight, which is ranked the long way); eight independent entries per trip.
+__device__ __forceinline__ int rank_in_bucket(const uint64_t* k, const int32_t* p, int lo, int hi, int e, uint64_t key, int32_t pos)
 {
     int r = 0, u = lo;
+    if (key == ~0ull)
+    {
+        for (; u < hi; ++u) r += less(k[u], p[u], key, pos) ? 1 : 0;
+        return r;
+    }
+    const uint64_t key1 = key + 1;
     for (; u + 8 <= hi; u += 8)
     {
         uint64_t kk[8];
-        int32_t pp[8];
 #pragma unroll
-        for (int v = 0; v < 8; ++v)
-        {
-            kk[v] = k[u + v];
-            pp[v] = p[u + v];
-        }
+        for (int v = 0; v < 8; ++v) kk[v] = k[u + v];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) r += less(kk[v], pp[v], key, pos) ? 1 : 0;
+        for (int v = 0; v < 8; ++v) r += kk[v] < ((u + v < e) ? key1 : key) ? 1 : 0;
     }
-    for (; u < hi; ++u) r += less(k[u], p[u], key, pos) ? 1 : 0;
+    for (; u < hi; ++u) r += k[u] < ((u < e) ? key1 : key) ? 1 : 0;
     return r;
 }
 
@@ -326,7 +330,7 @@ __device__ __forceinline__ int count_less(const uint64_t* k, const int32_t* p, i
 // ranks its element inside its own bucket (about 200 elements per workgroup: one per thread; the largest of 1024 buckets
 // holds 3-4 times the mean and sets the time: one wavefront per bucket took 58 us, this form 26 us, of which 5 us are
 // everything but the comparisons: 64-bit integer compares and the mask logic of the composite order are what is left).
-constexpr int GROUP = 2;
+constexpr int GROUP = 1;
 constexpr int GROUP_CAP = 2048;  // elements of one group ranked in LDS (24 KB)
 template <typename V>
 __global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V* out_vals, int lds_cap /* <= GROUP_CAP */)
@@ -362,7 +366,7 @@ __global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V*
         {
             const uint64_t k = sk[e];
             const int32_t p = sp[e];
-            r = count_less(sk, sp, lo, hi, k, p);
+            r = rank_in_bucket(sk, sp, lo, hi, e, k, p);
             out_vals[first + lo + r] = vals[p];
         }
         else
@@ -370,7 +374,7 @@ __global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V*
             // does not fit: the same ranking from memory (only skewed samples lead here)
             const uint64_t k = s.key2[first + e];
             const int32_t p = s.pos2[first + e];
-            r = count_less(s.key2 + first, s.pos2 + first, lo, hi, k, p);
+            r = rank_in_bucket(s.key2 + first, s.pos2 + first, lo, hi, e, k, p);
             out_vals[first + lo + r] = vals[p];
         }
     }
