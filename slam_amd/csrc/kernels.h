@@ -454,6 +454,10 @@ struct TileArgs
     const int32_t* freelist;  // ids of the free tiles (as of the last collection)
     int* ctrl;                // [0] allocation cursor into freelist, [1] number of free tiles, [2] error flag
     int lds_entries;          // > 0: the kernel was launched with 4 * lds_entries * 4 bytes of dynamic LDS for the tables
+    // copies fused into k_weights_S2<true> (null: k_tile_copy has made them): particle p copies the tiles of table
+    // slots plan_t[pos], pos in [plan_rng[2p], plan_rng[2p] + plan_rng[2p + 1]), into the free tiles freelist[pos]
+    const int32_t* plan_rng;
+    const int32_t* plan_t;
 };
 
 struct TiledMap
@@ -1054,6 +1058,7 @@ __global__ void __launch_bounds__(256) k_set_sectors(SectorTable t, float* out) 
 struct TilePlan
 {
     int32_t *wl_p, *wl_t;  // work list, indexed like the free list: particle and tile slot (wl_p < 0: nothing to do)
+    int32_t* rng;          // per particle: first position and number of its entries (they are consecutive)
 };
 
 // `sector_r[k]`, k = 0..255: how far the scan can write in the directions of sector k of the scan frame
@@ -1133,6 +1138,7 @@ __global__ void __launch_bounds__(1024) k_tile_plan(int64_t n, const double* x, 
             cx.tcols = ta.tcols;
             cx.tab_p = ta.tab + (size_t)p * ta.tiles_per_map;
             cx.sector_r = sector_r;
+            const int run0 = running;
             for (int q0 = 0; q0 < side * side; q0 += 64)
             {
                 int t;
@@ -1151,6 +1157,11 @@ __global__ void __launch_bounds__(1024) k_tile_plan(int64_t n, const double* x, 
                         ta.ctrl[2] = 1;  // pool exhausted
                 }
                 running += __builtin_popcountll(vote);
+            }
+            if (pass == 1 && lane == 0)
+            {
+                pl.rng[2 * p] = base_s + wave_off + run0;
+                pl.rng[2 * p + 1] = running - run0;
             }
         }
         if (pass == 0)

@@ -92,6 +92,7 @@ struct slam_mcl
     uint8_t* tile_pool = nullptr;
     int32_t *tile_tab = nullptr, *tile_tab2 = nullptr, *tile_free = nullptr;
     int32_t *tile_wl_p = nullptr, *tile_wl_t = nullptr;  // work list of k_tile_plan / k_tile_copy
+    int32_t* tile_rng = nullptr;                          // per particle: its range of the work list
     int *tile_ref = nullptr, *tile_who = nullptr, *tile_shared = nullptr;  // per tile: live mark, winning entry, shared mark
     int* tile_ctrl = nullptr;                                              // cursor, free count, error flag, cursor before the plan
     uint8_t* tile_dense = nullptr;     // one dense canvas (import / export staging)
@@ -235,6 +236,7 @@ struct Tuning
     int ss_lds_cap;  // SLAM_SS_LDS_CAP: largest group of buckets the sample sort ranks in LDS (tests force the path from memory)
     int fast_div;    // SLAM_FAST_DIV: 1 = the particle-lane kernel forms xarg / stddev from the reciprocal (same bits), 0 = divides
     int clamp_limit; // SLAM_RAY_CLAMP_LIMIT: 1 = the localization hit search stops beyond z + 4 sigma (default), 0 = always to max_dist
+    int tile_fuse;   // SLAM_TILE_FUSE: 1 = the two-phase kernel makes the planned tile copies itself (default), 0 = k_tile_copy before it
 };
 const Tuning& tuning()
 {
@@ -244,7 +246,7 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_TILE_FUSE", 1)};
     return t;
 }
 
@@ -487,7 +489,8 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             const int side = std::min(std::min(2 * (int)std::ceil(std::fmin(range, 1.0e6) / 64.0) + 3, span), 31);
             const int64_t per = std::min<int64_t>((int64_t)side * side, h->tile_T);
             const int64_t blocks = std::min<int64_t>(std::min<int64_t>(h->n * per, h->tile_cap), 16384);
-            slamk::TilePlan pl = {h->tile_wl_p, h->tile_wl_t};
+            slamk::TilePlan pl = {h->tile_wl_p, h->tile_wl_t, h->tile_rng};
+            const bool fuse = two_phase && tuning().tile_fuse != 0;
             {
                 // per sector of the scan frame (sector k covers angles [-pi + k 2pi/256, ...)): the farthest write
                 float sec[256] = {0.0f};
@@ -510,7 +513,13 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             hipLaunchKernelGGL(slamk::k_tile_mark, dim3(1), dim3(1), 0, h->stream, h->tile_ctrl);
             hipLaunchKernelGGL(slamk::k_tile_plan, dim3((unsigned)cdiv(h->n, 16 * slamk::TILE_PLAN_PW)), dim3(1024), 0, h->stream, h->n, h->x, h->y, h->th, a.sd,
                                a.stheta, a.srot, range, h->tile_sector, h->rows, h->cols, side, ta, pl);
-            hipLaunchKernelGGL(slamk::k_tile_copy, dim3((unsigned)blocks), dim3(256), 0, h->stream, ta, pl);
+            if (fuse)
+            {
+                ta.plan_rng = h->tile_rng;
+                ta.plan_t = h->tile_wl_t;
+            }
+            else
+                hipLaunchKernelGGL(slamk::k_tile_copy, dim3((unsigned)blocks), dim3(256), 0, h->stream, ta, pl);
             copies.reset();
             wspan.reset(new slam_mcl::Span(h, G_WEIGHTS));
             size_t lds = 0;
@@ -838,7 +847,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
                     h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
                     h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->ss_tmp, h->wlin, h->wmax,
                     h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_who, h->tile_shared, h->tile_ctrl, h->tile_dense, h->tile_sector,
-                    h->tile_wl_p, h->tile_wl_t, h->pack_stamp, h->pack_ctr, h->pack_slot, h->dev_bad};
+                    h->tile_wl_p, h->tile_wl_t, h->tile_rng, h->pack_stamp, h->pack_ctr, h->pack_slot, h->dev_bad};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (int k = 0; k < slam_mcl::SCAN_RING; ++k)
@@ -993,6 +1002,7 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
         TRY(dev_alloc(&h->tile_free, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_wl_p, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_wl_t, (size_t)h->tile_cap));
+        TRY(dev_alloc(&h->tile_rng, 2 * (size_t)n));
         TRY(dev_alloc(&h->tile_ref, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_who, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_shared, (size_t)h->tile_cap));

@@ -375,6 +375,64 @@ __global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta,
     if (TILED)
     {
         tmap.tab = ta.tab + (size_t)p * ta.tiles_per_map;
+        if (ta.plan_rng)
+        {
+            // The deferred deep copy of slam/mcl.cpp:147-155, made here instead of by k_tile_copy: the tiles k_tile_plan
+            // listed for this particle are copied by its own wavefront, four tiles (16 loads of 16 bytes per lane) in
+            // flight at a time: no launch and no work list of its own.  The copy phases (HBM) and the walk phases
+            // (instruction issue) of different wavefronts overlap little: 2-3 % on the step.  Measured and dropped:
+            // starting the first generation of wavefronts spread over 200-900 us (another 0-4 %, not reproducible), and
+            // reading the next ray's cells ahead of time to warm the L2 (slower at 1000 and at 125 000 particles:
+            // the wavefront is bound by its own instruction chain, not by the latency of its loads).
+            const int start =ta.plan_rng[2 * p], cnt_all = ta.plan_rng[2 * p + 1];
+            const int nfree = ta.ctrl[1];  // positions beyond the free list were not planned (pool exhausted: flagged there)
+            for (int c0 = 0; c0 < cnt_all; c0 += 64)
+            {
+                const int pos = start + c0 + lane;
+                const bool valid = c0 + lane < cnt_all && pos < nfree;
+                int t = 0, nid = 0, old = 0;
+                if (valid)
+                {
+                    t = ta.plan_t[pos];
+                    nid = ta.freelist[pos];
+                    old = tmap.tab[t] & ~TILE_OWN;
+                }
+                const int m = __builtin_popcountll(__ballot(valid));  // the valid lanes are the first m
+                int u = 0;
+                for (; u + 4 <= m; u += 4)
+                {
+                    uint4 v[4][TILE_BYTES / 16 / 64];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        const uint4* from = reinterpret_cast<const uint4*>(ta.pool + (size_t)(unsigned)bcast_i32(old, u + k) * TILE_BYTES);
+#pragma unroll
+                        for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) v[k][q] = from[q * 64 + lane];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                    {
+                        uint4* to = reinterpret_cast<uint4*>(ta.pool + (size_t)(unsigned)bcast_i32(nid, u + k) * TILE_BYTES);
+#pragma unroll
+                        for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) to[q * 64 + lane] = v[k][q];
+                    }
+                }
+                for (; u < m; ++u)
+                {
+                    const uint4* from = reinterpret_cast<const uint4*>(ta.pool + (size_t)(unsigned)bcast_i32(old, u) * TILE_BYTES);
+                    uint4* to = reinterpret_cast<uint4*>(ta.pool + (size_t)(unsigned)bcast_i32(nid, u) * TILE_BYTES);
+                    uint4 v[TILE_BYTES / 16 / 64];
+#pragma unroll
+                    for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) v[q] = from[q * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) to[q * 64 + lane] = v[q];
+                }
+                if (valid) tmap.tab[t] = nid | TILE_OWN;
+            }
+            // the copies and the table before the window and the cell loads below
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         // window origin: every reachable cell lies within max_iter cells of the start cell (a start far
         // outside the canvas reaches nothing: clamped only to keep the arithmetic in range)
         const int reach = npass * 64;
