@@ -479,15 +479,18 @@ __global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta,
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
                 {
-                    uint32_t rw = 0, cw = 0;
+                    // the low bits of the 32 row / column indices, one funnel shift per sample (sample s ends at bit s); a
+                    // cell index moves by at most one per sample, so "changed" = "parity changed"
+                    uint32_t par_r = 0, par_c = 0;
+                    const uint32_t before_r = (uint32_t)pi & 1u, before_c = (uint32_t)pj & 1u;
 #pragma unroll
                     for (int s = 0; s < 32; ++s)
                     {
                         x += dx;
                         y += dy;
                         const int ni = slam_f2i((rows_d - y) - 1.0), nj = slam_f2i(x);
-                        rw |= (uint32_t)((ni - pi) & 1) << s;
-                        cw |= (uint32_t)((nj - pj) & 1) << s;
+                        par_r = __builtin_amdgcn_alignbit((uint32_t)ni, par_r, 1);
+                        par_c = __builtin_amdgcn_alignbit((uint32_t)nj, par_c, 1);
                         pi = ni;
                         pj = nj;
                         if ((s & 15) == 15)
@@ -509,6 +512,7 @@ __global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta,
                             }
                         }
                     }
+                    const uint32_t rw = par_r ^ ((par_r << 1) | before_r), cw = par_c ^ ((par_c << 1) | before_c);
                     w[h] = rw;
                     w[2 + h] = cw;
                     cnt_r += (unsigned)__builtin_popcount(rw);
