@@ -48,7 +48,7 @@ enum
                                              second kernel in beam order */
     SLAM_RAYCAST_TWO_PHASE = 4,           /* SLAM mode, force: geometry of 64 rays at once (lane = beam), then the rays
                                              in order, 64 samples per pass (what SLAM_RAYCAST_FAST picks in SLAM mode
-                                             below 262144 particles; 2 forces the older wave-per-ray form) */
+                                             below 262144 particles and on tiles; 2 forces the older wave-per-ray form) */
     SLAM_RAYCAST_TWO_PHASE_LITERAL = 5,   /* test hook: the two-phase kernel with every batch of beams on its literal
                                              fallback loop (taken by itself only when rounding makes a cell index move by
                                              two in one sample) */
@@ -94,8 +94,8 @@ typedef struct slam_mcl_params
                               slam/mcl.cpp:147-155 does.  SLAM_MAPS_TILED: canvases are tables of 64x64
                               copy-on-write tiles in a shared pool; the resample copies tables, a tile
                               is copied when a particle that shares it is about to write it
-                              (SURVEY.md §8f row 3).  SLAM_MAPS_AUTO (0): tiled, except for shards and
-                              for n_particles >= 262144 (not built on tiles yet): dense */
+                              (SURVEY.md §8f row 3).  SLAM_MAPS_AUTO (0): tiled; dense for shards and
+                              for n_particles >= 262144 whose dense canvases fit 64 GiB */
     int32_t reserved;
     int64_t tile_pool_tiles; /* SLAM_MAPS_TILED: tiles (4 KiB each) in the pool; 0 = 1.5 x particles x
                                 tiles per canvas, which can never run out */

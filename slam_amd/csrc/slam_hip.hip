@@ -475,7 +475,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         const size_t s2_lds = 512 + (size_t)npass * 1024 + (h->tiled ? (size_t)win_w * win_w * 4 : 0);
         const bool two_phase = s2_lds <= 60 * 1024 && tuning().s_kernel != 1 &&
                                (h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE || h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE_LITERAL ||
-                                (h->prm.raycaster == SLAM_RAYCAST_FAST && wave));
+                                (h->prm.raycaster == SLAM_RAYCAST_FAST && (wave || h->tiled)));  // tiles: at any particle count
         const int s2_literal = (tuning().s_kernel == 2 || h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE_LITERAL) ? 1 : 0;
         if ((h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE || h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE_LITERAL) && !two_phase)
             return fail(SLAM_ERR_ARG, "SLAM_RAYCAST_TWO_PHASE: max_dist too large for the LDS of one wavefront");
@@ -985,7 +985,12 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
     if (!rc && (h->prm.map_storage < SLAM_MAPS_AUTO || h->prm.map_storage > SLAM_MAPS_TILED))
         rc = fail(SLAM_ERR_ARG, "map_storage must be SLAM_MAPS_AUTO, SLAM_MAPS_DENSE or SLAM_MAPS_TILED");
     if (!rc && h->prm.map_storage == SLAM_MAPS_AUTO)
-        h->prm.map_storage = (n == h->n_glob && n < 262144) ? SLAM_MAPS_TILED : SLAM_MAPS_DENSE;
+    {
+        // dense canvases only where the one-thread-per-particle kernel takes over (262144 particles and more) AND the
+        // two copies of every canvas fit a quarter of the HBM; maze-sized canvases never do: tiles
+        const double dense_bytes = 2.0 * (double)n * (double)(((size_t)h->rows * h->cols + 255) / 256 * 256);
+        h->prm.map_storage = (n == h->n_glob && (n < 262144 || dense_bytes > 64.0 * 1073741824.0)) ? SLAM_MAPS_TILED : SLAM_MAPS_DENSE;
+    }
     if (!rc && h->prm.mode == SLAM_MODE_SLAM && h->prm.map_storage == SLAM_MAPS_TILED)
     {
         h->tiled = true;

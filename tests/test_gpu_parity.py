@@ -1354,6 +1354,46 @@ def test_full_shard_size_of_config_4_grid_slam(sa):
     small.close(), f.close(), gm.close()
 
 
+def test_tiled_canvases_beyond_262144_particles(sa):
+    """SLAM_MAPS_AUTO on canvases too large to hold dense (300 000 x 2354 x 2464 x 2 = 3.5 TB) picks tiles, and the
+    two-phase kernel runs on them at that particle count (round 1 fell back to dense storage from 262 144 on): a
+    random subset recomputed by the literal one-thread-per-particle kernel on dense canvases gives the same weights
+    and canvases bit for bit over three steps; the pool never runs dry."""
+    N, B, rows, cols = 300_000, 24, 2354, 2464
+    free = orc.load_map("maze")
+    rng = np.random.default_rng(11)
+    gm = sa.GridMap(free.astype(np.uint8))
+    pool = 8_000_000  # 32 GB
+    f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=0xB16, sort=sa.capi.SORT_NONE, tile_pool_tiles=pool)
+    assert f.tile_stats()["pool"] == pool  # AUTO chose tiles
+    S = 32
+    small = sa.Filter(S, rows, cols, mode=sa.capi.MODE_SLAM, sort=sa.capi.SORT_NONE, map_storage=sa.capi.MAPS_DENSE,
+                      raycaster=sa.capi.RAYCAST_FAST_PARTICLE_LANES)
+    true = [1944.5, 2188.5, np.pi / 2]
+    for step in range(3):
+        true = [true[0] + 2.5 * np.cos(true[2]), true[1] + 2.5 * np.sin(true[2]), true[2]]
+        sensor = orc.sensor_position(true, OFFSET, orc.DET)
+        ang, dist = orc.hits_to_scan(gm.fake_lidar_scan(sensor, 0.0, 2 * np.pi, 60.0, B)[0], sensor, 0.0, 2 * np.pi, 60.0)
+        f.predict([0.0, 2.5, 0.0], [1e-3] * 4)
+        x, y, th = f.poses()
+        sub = np.sort(rng.choice(N, S, replace=False))
+        before = np.stack([f.map_of(int(p)) for p in sub])
+        f.update_weights(ang, dist, 5.0, 60.0, OFFSET)
+        w = f.weights()
+        ts = f.tile_stats()
+        assert ts["live"] + ts["allocated_since"] < pool
+        small.set_poses(x[sub], y[sub], th[sub])
+        small.set_maps(before)
+        small.update_weights(ang, dist, 5.0, 60.0, OFFSET)
+        assert_bits(w[sub], small.weights(), f"step {step}: subset recomputed on dense canvases")
+        for k, p in enumerate(sub):
+            assert np.array_equal(f.map_of(int(p)), small.map_of(k)), f"step {step}: canvas of particle {p}"
+        f.resample()
+        idx = f.last_indices()
+        assert idx.min() >= 0 and idx.max() < N
+    small.close(), f.close(), gm.close()
+
+
 # ---- BASELINE configs[2] and [4] at reduced particle counts: synthetic grids, long ranges, seeding ----
 def test_seeding_matches_host_replay(sa):
     from slam_amd import synth
