@@ -1110,6 +1110,7 @@ __global__ void __launch_bounds__(1024) k_tile_plan(int64_t n, const double* x, 
                                                     int cols, int side, TileArgs ta, TilePlan pl)
 {
     __shared__ int cnt_s, base_s;
+    __shared__ uint64_t votes_s[16][TILE_PLAN_PW][16];  // the votes of the counting pass (side <= 31: at most 16 x 64 tiles)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) cnt_s = 0;
     __syncthreads();
@@ -1142,8 +1143,20 @@ __global__ void __launch_bounds__(1024) k_tile_plan(int64_t n, const double* x, 
             for (int q0 = 0; q0 < side * side; q0 += 64)
             {
                 int t;
-                const bool need = cx.need(q0 + lane, &t);
-                const uint64_t vote = __ballot(need);
+                bool need;
+                uint64_t vote;
+                if (pass == 0)
+                {
+                    need = cx.need(q0 + lane, &t);
+                    vote = __ballot(need);
+                    if (lane == 0) votes_s[wave][k][q0 >> 6] = vote;
+                }
+                else
+                {
+                    vote = votes_s[wave][k][q0 >> 6];
+                    need = __builtin_amdgcn_inverse_ballot_w64(vote);
+                    t = (cx.ti_first + (q0 + lane) / side) * cx.tcols + cx.tj_first + (q0 + lane) % side;
+                }
                 if (pass == 1 && need)
                 {
                     const int pos = base_s + wave_off + running +
