@@ -111,8 +111,13 @@ int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out);
 void slam_mcl_destroy(slam_mcl* h);
 
 /* Localization mode: the shared occupancy grid, row-major uint8, hit test `< 128` as in
- * slam/raycast.cpp:183-184.  Builds the clearance grid used by SLAM_RAYCAST_FAST. */
+ * slam/raycast.cpp:183-184.  Uploads the map and builds the clearance planes used by SLAM_RAYCAST_FAST
+ * on the device (41 ms for a 16384 x 16384 map). */
 int slam_mcl_set_map_u8(slam_mcl* h, const uint8_t* map, int32_t rows, int32_t cols);
+/* The clearance planes set_map_u8 built (no reference counterpart: inspection and tests): n_planes x plane_stride
+ * bytes, each plane (rows + 4) x (cols + 4) with a two-cell frame; 8 cone-clearance planes (one per octant of the ray
+ * direction), or 1 Chebyshev plane for maps too large for 32-bit plane offsets.  out == NULL: sizes only. */
+int slam_mcl_get_clearance(slam_mcl* h, uint8_t* out, int64_t capacity_bytes, int32_t* n_planes, int64_t* plane_stride);
 
 /* Particle seeding / direct state access (no reference counterpart beyond reset_particles). */
 int slam_mcl_set_poses(slam_mcl* h, const double* x, const double* y, const double* theta, int64_t first, int64_t count);

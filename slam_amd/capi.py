@@ -77,6 +77,7 @@ SYMBOLS = {
     "slam_mcl_create": (ctypes.c_int, [ctypes.POINTER(Params), ctypes.POINTER(_P)]),
     "slam_mcl_destroy": (None, [_P]),
     "slam_mcl_set_map_u8": (ctypes.c_int, [_P, _P, _I32, _I32]),
+    "slam_mcl_get_clearance": (ctypes.c_int, [_P, _P, _I64, _P, _P]),
     "slam_mcl_set_poses": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64]),
     "slam_mcl_seed_gaussian": (ctypes.c_int, [_P, _P, _P]),
     "slam_mcl_seed_uniform_free": (ctypes.c_int, [_P]),

@@ -16,6 +16,7 @@
 
 #include "../../include/slam_hip.h"
 #include "clearance.h"
+#include "cone_gpu.h"
 #include "kernels.h"
 #include "sortk.h"
 
@@ -236,6 +237,7 @@ struct Tuning
     int ss_lds_cap;  // SLAM_SS_LDS_CAP: largest group of buckets the sample sort ranks in LDS (tests force the path from memory)
     int fast_div;    // SLAM_FAST_DIV: 1 = the particle-lane kernel forms xarg / stddev from the reciprocal (same bits), 0 = divides
     int clamp_limit; // SLAM_RAY_CLAMP_LIMIT: 1 = the localization hit search stops beyond z + 4 sigma (default), 0 = always to max_dist
+    int cone_build;  // SLAM_CONE_BUILD: 1 = the cone-clearance planes are built on the device (default), 0 = on the host
     int tile_fuse;   // SLAM_TILE_FUSE: 1 = the two-phase kernel makes the planned tile copies itself (default), 0 = k_tile_copy before it
 };
 const Tuning& tuning()
@@ -246,7 +248,7 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_TILE_FUSE", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_TILE_FUSE", 1)};
     return t;
 }
 
@@ -547,7 +549,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         // lane = particle; (64-particle block, beam segment) work items; see k_rays_pl
         a.grid = h->clr;
         a.map_stride = h->clr_stride;
-        const size_t cap_max = (size_t)64 << 20;  // 512 MiB of scratch at most
+        const size_t cap_max = (size_t)64 << 20;  // 512 MiB of scratch at most (two launches with slabs that fit the 256 MB cache: 4 % slower)
         const int64_t pblocks_all = cdiv(h->n, 64);
         // enough particle blocks to fill the chip several times over: one launch, whole scans per lane, no slab
         const bool direct = h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT ||
@@ -1074,15 +1076,41 @@ SLAM_API int slam_mcl_set_map_u8(slam_mcl* h, const uint8_t* map, int32_t rows, 
     {
         if ((rc = dev_alloc(&h->grid, bytes)) || (rc = dev_alloc(&h->clr, pbytes))) return rc;
     }
-    std::vector<uint8_t> E(pbytes);
-    if (cone)
-        slam_build_cone_clearance_padded(map, rows, cols, E.data());
-    else
-        slam_build_clearance_padded(map, rows, cols, E.data());
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->grid, map, bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->clr, E.data(), pbytes, hipMemcpyHostToDevice));
+    if (cone && tuning().cone_build)
+    {
+        // the planes from the resident raw map (cone_gpu.h): only the map itself crosses PCIe
+        hipError_t e = slam_build_cone_planes_device(h->grid, rows, cols, h->clr, h->clr_stride, h->stream);
+        if (e != hipSuccess) return fail(SLAM_ERR_HIP, std::string("cone-clearance planes: ") + hipGetErrorString(e));
+    }
+    else
+    {
+        std::vector<uint8_t> E(pbytes);
+        if (cone)
+            slam_build_cone_clearance_padded(map, rows, cols, E.data());
+        else
+            slam_build_clearance_padded(map, rows, cols, E.data());
+        HIPCHK(hipMemcpy(h->clr, E.data(), pbytes, hipMemcpyHostToDevice));
+    }
     h->have_map = true;
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_get_clearance(slam_mcl* h, uint8_t* out, int64_t capacity_bytes, int32_t* n_planes, int64_t* plane_stride)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_LOCALIZATION || !h->have_map) return fail(SLAM_ERR_STATE, "get_clearance: no map set");
+    const bool cone = h->clr_stride != 0;
+    const int64_t stride = cone ? (int64_t)h->clr_stride : (int64_t)(h->rows + 4) * (int64_t)(h->cols + 4);
+    const int planes = cone ? 8 : 1;
+    if (n_planes) *n_planes = planes;
+    if (plane_stride) *plane_stride = stride;
+    if (!out) return SLAM_OK;
+    if (capacity_bytes < planes * stride) return fail(SLAM_ERR_ARG, "get_clearance: buffer too small");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->clr, (size_t)(planes * stride), hipMemcpyDeviceToHost));
     return SLAM_OK;
 }
 

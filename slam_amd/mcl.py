@@ -82,6 +82,16 @@ class Filter:
         g = np.ascontiguousarray(grid_u8, dtype=np.uint8)
         check(self.lib.slam_mcl_set_map_u8(self._h, ptr(g), g.shape[0], g.shape[1]), self.lib)
 
+    def clearance(self):
+        """The clearance planes built by set_map: array (n_planes, plane_stride) of uint8 (slam_mcl_get_clearance)."""
+        import ctypes
+
+        n, stride = ctypes.c_int32(0), ctypes.c_int64(0)
+        check(self.lib.slam_mcl_get_clearance(self._h, None, 0, ctypes.byref(n), ctypes.byref(stride)), self.lib)
+        out = np.empty((n.value, stride.value), dtype=np.uint8)
+        check(self.lib.slam_mcl_get_clearance(self._h, ptr(out), out.size, ctypes.byref(n), ctypes.byref(stride)), self.lib)
+        return out
+
     def set_poses(self, x, y, theta, first=0):
         x, y, theta = f64(x), f64(y), f64(theta)
         check(self.lib.slam_mcl_set_poses(self._h, ptr(x), ptr(y), ptr(theta), first, x.size), self.lib)

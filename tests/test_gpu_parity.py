@@ -303,6 +303,37 @@ def test_particle_lane_kernel_that_sums_its_own_beams(sa):
         sa.Filter(16, 64, 64, mode=sa.capi.MODE_SLAM, raycaster=sa.capi.RAYCAST_FAST_PARTICLE_LANES_DIRECT)
 
 
+def test_cone_planes_built_on_the_device_equal_the_host_construction(sa):
+    """slam_mcl_set_map_u8 builds the eight cone-clearance planes on the device (cone_gpu.h) from the resident raw map;
+    they must equal the host construction of clearance.h (itself checked against the brute-force definition on the CPU,
+    tests/test_ray_host.py) byte for byte, frames and padding of the stride aside: random maps of awkward sizes (rows
+    and columns around the 64-cell chunks of the row scan), densities from empty to full, and the two real maps."""
+    import ctypes
+
+    hh = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_harness", "libray_harness.so"))
+    hh.hh_cone_plane_stride.restype = ctypes.c_ulong
+    P = ctypes.c_void_p
+    rng = np.random.default_rng(77)
+    cases = [(rng.integers(1, 200), rng.integers(1, 200), d) for d in (0.0, 0.002, 0.05, 0.3, 1.0) for _ in range(3)]
+    cases += [(59, 60, 0.03), (60, 124, 0.03), (61, 188, 0.01), (300, 63, 0.01), (1, 1, 0.0), (2, 700, 0.004), (700, 2, 0.004)]
+    grids = [np.where(rng.random((int(r), int(c))) < d, 0, 255).astype(np.uint8) for r, c, d in cases]
+    grids += [(orc.load_map("floor_plan") * 255).astype(np.uint8), (orc.load_map("maze") * 255).astype(np.uint8)]
+    for g in grids:
+        rows, cols = g.shape
+        f = sa.Filter(8, rows, cols)
+        f.set_map(g)
+        got = f.clearance()
+        f.close()
+        stride = hh.hh_cone_plane_stride(rows, cols)
+        assert got.shape == (8, stride)
+        want = np.zeros(8 * stride, dtype=np.uint8)
+        hh.hh_build_cone_planes(g.ctypes.data_as(P), rows, cols, want.ctypes.data_as(P))
+        n = (rows + 4) * (cols + 4)
+        for o in range(8):
+            a, b = got[o, :n].reshape(rows + 4, cols + 4), want[o * stride:o * stride + n].reshape(rows + 4, cols + 4)
+            assert np.array_equal(a, b), f"plane {o} of a {rows}x{cols} map: {np.argwhere(a != b)[:5]}"
+
+
 def test_one_chebyshev_plane_in_place_of_the_cone_planes(sa, tmp_path):
     """Maps too large for eight planes below 4 GiB get ONE plane of Chebyshev clearance (plane stride 0).  The choice is
     made when the map is set; SLAM_CONE_PLANES=0 forces it in a child process, whose weights and hits must equal the ones
