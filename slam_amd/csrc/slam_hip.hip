@@ -512,7 +512,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 // travels as a kernel argument: a copy from pageable memory would make the host wait for the stream
                 hipLaunchKernelGGL(slamk::k_set_sectors, dim3(1), dim3(256), 0, h->stream, dil, h->tile_sector);
             }
-            hipLaunchKernelGGL(slamk::k_tile_mark, dim3(1), dim3(1), 0, h->stream, h->tile_ctrl);
+            if (!fuse) hipLaunchKernelGGL(slamk::k_tile_mark, dim3(1), dim3(1), 0, h->stream, h->tile_ctrl);  // (where k_tile_copy starts)
             hipLaunchKernelGGL(slamk::k_tile_plan, dim3((unsigned)cdiv(h->n, 16 * slamk::TILE_PLAN_PW)), dim3(1024), 0, h->stream, h->n, h->x, h->y, h->th, a.sd,
                                a.stheta, a.srot, range, h->tile_sector, h->rows, h->cols, side, ta, pl);
             if (fuse)
