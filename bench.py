@@ -104,7 +104,7 @@ def cpu_baseline(free, ang, dist, n_beams, budget_s=12.0):
 
     n0 = 64 * cores
     t = run(n0)
-    n = int(max(n0, min(200000, n0 * budget_s / max(t, 1e-3))))
+    n = int(max(n0, min(400000, n0 * budget_s / max(t, 1e-3))))
     t = run(n)
     return {"value": n * n_beams / t, "unit": "particle-beams/s", "cores": cores, "kind": "port",
             "sample": f"{n} particles x {n_beams} beams of the same workload, one full step (predict+update), "
