@@ -24,6 +24,13 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 }
 
 // value of `v` in lane `l` for a wave-uniform l: a scalar read instead of an LDS permute
+// 16-byte store that does not stay in the L2 (bulk copies whose lines are not read again soon: keeping them evicts
+// the lines the walks re-read; on the fused tile copies of k_weights_S2 this took the kernel from 24.5 to 17.5 ms)
+typedef unsigned int slam_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_streaming(uint4* to, const uint4& v)
+{
+    __builtin_nontemporal_store(*reinterpret_cast<const slam_u32x4*>(&v), reinterpret_cast<slam_u32x4*>(to));
+}
 __device__ __forceinline__ int bcast_i32(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
 __device__ __forceinline__ double bcast_f64(double v, int l) { return readlane_f64(v, __builtin_amdgcn_readfirstlane(l)); }
 // value of `v` one lane below (lane 0 keeps its own): a DPP wave shift instead of an LDS permute
@@ -963,7 +970,7 @@ __global__ void __launch_bounds__(256) k_clone_maps(const uint8_t* maps, uint8_t
     uint4* to = reinterpret_cast<uint4*>(maps2 + stride * p);
     const size_t n16 = stride / 16;
     for (size_t t = (size_t)blockIdx.y * blockDim.x + threadIdx.x; t < n16; t += (size_t)gridDim.y * blockDim.x)
-        to[t] = from[t];
+        store_streaming(&to[t], from[t]);
 }
 
 // ---- tiled canvases: table gather at resample, collection of unreferenced tiles, import / export ----
@@ -1205,7 +1212,7 @@ __global__ void __launch_bounds__(256) k_tile_copy(TileArgs ta, TilePlan pl)
         const int nid = ta.freelist[pos];
         const uint4* from = reinterpret_cast<const uint4*>(ta.pool + (size_t)old * TILE_BYTES);
         uint4* to = reinterpret_cast<uint4*>(ta.pool + (size_t)nid * TILE_BYTES);
-        to[threadIdx.x] = from[threadIdx.x];
+        store_streaming(&to[threadIdx.x], from[threadIdx.x]);
         __syncthreads();  // (the table entry is read above by every thread before thread 0 repoints it)
         if (threadIdx.x == 0)
         {

@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta,
                     {
                         uint4* to = reinterpret_cast<uint4*>(ta.pool + (size_t)(unsigned)bcast_i32(nid, u + k) * TILE_BYTES);
 #pragma unroll
-                        for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) to[q * 64 + lane] = v[k][q];
+                        for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) store_streaming(&to[q * 64 + lane], v[k][q]);
                     }
                 }
                 for (; u < m; ++u)
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta,
 #pragma unroll
                     for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) v[q] = from[q * 64 + lane];
 #pragma unroll
-                    for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) to[q * 64 + lane] = v[q];
+                    for (int q = 0; q < TILE_BYTES / 16 / 64; ++q) store_streaming(&to[q * 64 + lane], v[q]);
                 }
                 if (valid) tmap.tab[t] = nid | TILE_OWN;
             }
