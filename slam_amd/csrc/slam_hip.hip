@@ -485,7 +485,13 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         {
             // make every tile within sensor range exclusive up front (parallel), then walk
             std::unique_ptr<slam_mcl::Span> copies(new slam_mcl::Span(h, G_CLONE));
-            const double range = a.zmax + 3.0;
+            // (no farther than the scan's farthest write: min(z, zmax) + 2 over its beams, plus a cell of margin)
+            double range = 0.0;
+            {
+                const double* zz = h->scan_cache.data() + 2 * (size_t)B;
+                for (int b = 0; b < B; ++b) range = std::fmax(range, std::fmin(zz[b], a.zmax));
+                range = std::fmin(range, a.zmax) + 3.0;
+            }
             // (bounding square in tiles; capped: what it misses is copied inside the kernel)
             const int span = 2 * std::max(h->tile_T / h->tile_tc, h->tile_tc) + 1;
             const int side = std::min(std::min(2 * (int)std::ceil(std::fmin(range, 1.0e6) / 64.0) + 3, span), 31);
