@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
         if (DIRECT)
             acc += lw;  // slam/mcl.cpp:69-74
         else
-            slab[(size_t)b * 64] = lw;
+            __builtin_nontemporal_store(lw, &slab[(size_t)b * 64]);  // read once, by k_sum_lw: not to stay in the L2 that holds the planes
         if (RECORD)
         {
             const size_t o = (size_t)p * a.B + b;
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(256) k_sum_lw(WeightArgs a)
     {
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(b + u) * 64];
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(&slab[(size_t)(b + u) * 64]);
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u];
     }
