@@ -170,6 +170,7 @@ def slam_entry(sa, capi, device, label, n, rows, cols, free, true0, pool, steps,
                   async_launch=True)
     odom, alphas = [0.0, 2.5, 0.0], [1e-3] * 4
     k = 0
+    f.collect_stats(False)  # the cell counters are instrumentation: off in the timed steps, on where the bytes are counted
     for _ in range(warmup):
         f.predict(odom, alphas); f.update(*scans[k], STDDEV, MAX_DIST, OFFSET); k += 1
     f.synchronize()
@@ -180,6 +181,7 @@ def slam_entry(sa, capi, device, label, n, rows, cols, free, true0, pool, steps,
     ms_step = (time.perf_counter() - t0) / steps * 1e3
     # roofline of the walk kernel from the next steps, one at a time (the counters of a pass are read after it)
     f.profile(True)
+    f.collect_stats(True)
     f.kernel_ms()
     alg = 0.0
     reads = writes = 0.0
@@ -208,6 +210,7 @@ def slam_entry(sa, capi, device, label, n, rows, cols, free, true0, pool, steps,
     out = {
         "workload": label, "value": n * B / (ms_step * 1e-3), "unit": "particle-beams/s", "ms_per_step": ms_step, "steps": steps,
         "warmup": warmup, "dtype": "f64 positions / u8 cells",
+        "instrumentation": "cell counters (slam_mcl_get_stats) off in the timed steps, on in the steps kernel_avg_ms and the bytes come from",
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "k_weights_S2<tiled> (the planned copy-on-write tile copies = the deferred map clone, "
                                                    "then walk + occupancy update + beam likelihood)", "kernel_avg_ms": w_ms,

@@ -166,6 +166,9 @@ int slam_mcl_record_hits(slam_mcl* h, int32_t enable);
 int slam_mcl_average_pose(slam_mcl* h, double out[3]);
 /* Counters of the last update_weights: {cells read, cells written, steps}; SLAM_RAYCAST_WALK and SLAM mode only. */
 int slam_mcl_get_stats(slam_mcl* h, int64_t out[3]);
+/* The counters are instrumentation (the reference keeps none) and cost the grid-SLAM kernel about 5 %: on by default,
+ * enable = 0 switches them off (slam_mcl_get_stats then fails with SLAM_ERR_STATE), as slam_mcl_record_hits does for hits. */
+int slam_mcl_collect_stats(slam_mcl* h, int32_t enable);
 /* Accumulated device time (HIP events on the handle's stream) per kernel group since the last
  * reset: out[0] predict, [1] weights (the ray kernels), [2] resample (scan+select+gather), [3] sort, [4] map clone
  * (dense: the deep copy after the selection; tiles: table gather + census, and the copy-on-write copies made just

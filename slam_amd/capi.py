@@ -107,6 +107,7 @@ SYMBOLS = {
     "slam_mcl_get_prefix": (ctypes.c_int, [_P, _P, _P]),
     "slam_mcl_get_hits": (ctypes.c_int, [_P, _P, _P]),
     "slam_mcl_record_hits": (ctypes.c_int, [_P, _I32]),
+    "slam_mcl_collect_stats": (ctypes.c_int, [_P, _I32]),
     "slam_mcl_average_pose": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_stats": (ctypes.c_int, [_P, _P]),
     "slam_mcl_profile": (ctypes.c_int, [_P, _I32]),

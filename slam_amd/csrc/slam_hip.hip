@@ -88,6 +88,7 @@ struct slam_mcl
     double *wlin = nullptr, *wmax = nullptr;  // SLAM_WEIGHT_LOG: exp(lw - max) of all shards, max-reduction levels
     // SLAM_MAPS_TILED
     bool tiled = false;
+    bool collect_stats = true;  // slam_mcl_collect_stats
     int tile_T = 0, tile_tc = 0;       // tiles per canvas, per canvas row
     int64_t tile_cap = 0;              // tiles in the pool
     uint8_t* tile_pool = nullptr;
@@ -536,14 +537,20 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 ta.lds_entries = h->tile_T;
                 lds = (size_t)h->tile_T * 16;
             }
-            if (two_phase)
-                hipLaunchKernelGGL(slamk::k_weights_S2<true>, dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
+            if (two_phase && h->collect_stats)
+                hipLaunchKernelGGL((slamk::k_weights_S2<true, true>), dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
+                                   s2_literal);
+            else if (two_phase)
+                hipLaunchKernelGGL((slamk::k_weights_S2<true, false>), dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
                                    s2_literal);
             else
                 hipLaunchKernelGGL(slamk::k_weights_S_wave<true>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), lds, h->stream, a, ta);
         }
+        else if (two_phase && h->collect_stats)
+            hipLaunchKernelGGL((slamk::k_weights_S2<false, true>), dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
+                               s2_literal);
         else if (two_phase)
-            hipLaunchKernelGGL(slamk::k_weights_S2<false>, dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
+            hipLaunchKernelGGL((slamk::k_weights_S2<false, false>), dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
                                s2_literal);
         else if (wave)
             hipLaunchKernelGGL(slamk::k_weights_S_wave<false>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a, ta);
@@ -1662,11 +1669,20 @@ SLAM_API int slam_mcl_average_pose(slam_mcl* h, double out[3])
     return SLAM_OK;
 }
 
+SLAM_API int slam_mcl_collect_stats(slam_mcl* h, int32_t enable)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    h->collect_stats = enable != 0;
+    return SLAM_OK;
+}
+
 SLAM_API int slam_mcl_get_stats(slam_mcl* h, int64_t out[3])
 {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!out) return fail(SLAM_ERR_ARG, "null");
+    if (!h->collect_stats) return fail(SLAM_ERR_STATE, "get_stats: the counters are switched off (slam_mcl_collect_stats)");
     HIPCHK(hipStreamSynchronize(h->stream));
     unsigned long long t[3];
     HIPCHK(hipMemcpy(t, h->stats, sizeof(t), hipMemcpyDeviceToHost));

@@ -218,7 +218,7 @@ __device__ __forceinline__ int s2_first(uint64_t m) { return m ? __builtin_ctzll
 
 // Phase B of one ray.  All ray-level values are wave-uniform.  Returns the sample number of the hit
 // (0: none); the hit cell follows from the hit position.
-template <class MAP>
+template <bool STATS, class MAP>
 __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bits + q, stride 64 per pass */, int rows, int cols,
                                       int i0, int j0, int si, int sj, int k_far, int k_vfar, bool draw_occ, int max_iter,
                                       const uint8_t* luts, int lane, unsigned* n_read, unsigned* n_written, unsigned* n_steps)
@@ -283,11 +283,11 @@ __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bit
                     {
                         const int f = __builtin_ctzll(OCC);
                         khit = G0 + f + 1;
-                        steps = (unsigned)khit;
+                        if (STATS) steps = (unsigned)khit;
                         seen &= s2_below(f + 1);
                         done = true;
                     }
-                    reads += (unsigned)__builtin_popcountll(seen);
+                    if (STATS) reads += (unsigned)__builtin_popcountll(seen);
                     continue;
                 }
                 uint64_t W;         // lanes that write
@@ -301,7 +301,7 @@ __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bit
                         found = true;
                     }
                     W = cand[u];
-                    reads += (unsigned)__builtin_popcountll(W);
+                    if (STATS) reads += (unsigned)__builtin_popcountll(W);
                 }
                 else
                 {
@@ -326,10 +326,10 @@ __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bit
                         if (draw_occ) WOCC = 1ull << f_far;
                     }
                     W = (PROC & s2_below(Lfar - G0)) | WOCC;
-                    reads += (unsigned)__builtin_popcountll(PROC);
+                    if (STATS) reads += (unsigned)__builtin_popcountll(PROC);
                     if (term < 64)
                     {
-                        steps = (unsigned)(G0 + term + 1);
+                        if (STATS) steps = (unsigned)(G0 + term + 1);
                         done = true;
                     }
                 }
@@ -343,19 +343,23 @@ __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bit
                     to = r.ptr;
                 }
                 if (__builtin_amdgcn_inverse_ballot_w64(W)) *to = v;
-                writes += (unsigned)__builtin_popcountll(W);
+                if (STATS) writes += (unsigned)__builtin_popcountll(W);
             }
         }
         g += gn;
     }
-    *n_read += reads;
-    *n_written += writes;
-    *n_steps += steps;
+    if (STATS)
+    {
+        *n_read += reads;
+        *n_written += writes;
+        *n_steps += steps;
+    }
     return khit;
 }
 
 // LDS of one wavefront (dynamic): [512 B update tables][npass x 64 beams x 16 B geometry bits][win_w^2 x 4 B table window]
-template <bool TILED>
+// STATS: the counters of slam_mcl_get_stats (cells read, cells written, samples) are kept: about 5 % of the kernel
+template <bool TILED, bool STATS = true>
 __global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta, int npass, int win_w, int force_literal)
 {
     extern __shared__ __align__(16) unsigned char s2_lds[];
@@ -589,10 +593,10 @@ __global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta,
                 const bool draw_occ = bcast_f64(z2, q) != a.zmax2;  // slam/raycast.cpp:205
                 int khit;
                 if (TILED)
-                    khit = s2_ray(tmap, bits + q, a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
+                    khit = s2_ray<STATS>(tmap, bits + q, a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
                                   bcast_i32(k_vfar, q), draw_occ, max_iter, luts, lane, &r, &w, &st);
                 else
-                    khit = s2_ray(dmap, bits + q, a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
+                    khit = s2_ray<STATS>(dmap, bits + q, a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
                                   bcast_i32(k_vfar, q), draw_occ, max_iter, luts, lane, &r, &w, &st);
                 if (lane == q) my_khit = khit;
                 n_read += r;
@@ -642,7 +646,7 @@ __global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta,
     if (lane == 0)
     {
         a.w[p] = a.log_domain ? acc : dm_exp(acc);
-        if (a.stats)
+        if (STATS && a.stats)
         {
             atomicAdd(&a.stats[0], n_read);
             atomicAdd(&a.stats[1], n_written);

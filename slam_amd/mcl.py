@@ -246,6 +246,10 @@ class Filter:
         check(self.lib.slam_mcl_get_prefix(self._h, ptr(P), ptr(s)), self.lib)
         return P, float(s[0])
 
+    def collect_stats(self, enable=True):
+        """Counters of stats() on (default) or off: they are instrumentation and cost the grid-SLAM kernel about 5 %."""
+        check(self.lib.slam_mcl_collect_stats(self._h, 1 if enable else 0), self.lib)
+
     def record_hits(self, enable=True):
         check(self.lib.slam_mcl_record_hits(self._h, 1 if enable else 0), self.lib)
 

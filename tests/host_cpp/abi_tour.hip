@@ -142,7 +142,19 @@ static void localization()
         }
         OK(slam_mcl_predict(h, ODOM, ALPHAS));
         OK(slam_mcl_update(h, ang.data(), dist.data(), B, 5.0, 120.0, OFFSET));
-        if (variant == 0) OK(slam_mcl_get_stats(h, stats));
+        if (variant == 0)
+        {
+            OK(slam_mcl_get_stats(h, stats));
+            OK(slam_mcl_collect_stats(h, 0));
+            EXPECT(slam_mcl_get_stats(h, stats), SLAM_ERR_STATE);  // the counters are off
+            OK(slam_mcl_collect_stats(h, 1));
+            int32_t n_planes = 0;
+            int64_t plane_stride = 0;
+            OK(slam_mcl_get_clearance(h, nullptr, 0, &n_planes, &plane_stride));
+            std::vector<uint8_t> planes((size_t)n_planes * (size_t)plane_stride);
+            OK(slam_mcl_get_clearance(h, planes.data(), (int64_t)planes.size(), &n_planes, &plane_stride));
+            EXPECT(slam_mcl_get_clearance(h, planes.data(), 1, &n_planes, &plane_stride), SLAM_ERR_ARG);
+        }
         slam_mcl_destroy(h);
     }
     // two shards against one unsorted handle: whole and split exchange
