@@ -1055,7 +1055,21 @@ struct SectorTable
 {
     float r[256];
 };
-__global__ void __launch_bounds__(256) k_set_sectors(SectorTable t, float* out) { out[threadIdx.x] = t.r[threadIdx.x]; }
+// out[j * 256 + k] = max of the sectors k .. k + 2^j - 1 (cyclic), j = 0..5: the farthest write over any run of up to
+// 64 sectors is then two reads (k_tile_plan looked at up to 44 sectors per tile, one dependent read each)
+enum { SECTOR_LEVELS = 6 };
+__global__ void __launch_bounds__(256) k_set_sectors(SectorTable t, float* out)
+{
+    const int k = threadIdx.x;
+    float v = t.r[k];
+    out[k] = v;
+    for (int j = 1; j < SECTOR_LEVELS; ++j)
+    {
+        __syncthreads();
+        v = fmaxf(v, out[(j - 1) * 256 + ((k + (1 << (j - 1))) & 255)]);
+        out[j * 256 + k] = v;
+    }
+}
 
 // Before a weighting pass: every tile a particle may write (within `range` cells of its sensor) that
 // it does not own yet is copied to a fresh tile, instead of one at a time inside k_weights_S_wave.
@@ -1101,8 +1115,9 @@ struct TilePlanCtx
             const float alpha = atan2f(dyw, dxw) - (float)heading;
             const float half = asinf(46.0f / dcen) * inv + 1.5f;  // half-diagonal of a tile, plus margin, in sectors
             const int k0 = (int)floorf(alpha * inv - half), k1 = (int)floorf(alpha * inv + half);
-            float rmax = 0.0f;
-            for (int k = k0; k <= k1; ++k) rmax = fmaxf(rmax, sector_r[(k + 128) & 255]);
+            const int len = k1 - k0 + 1;  // 4 .. 44 (half <= asin(0.46) * inv + 1.5)
+            const int j = len >= 32 ? 5 : 31 - __builtin_clz(len);
+            const float rmax = fmaxf(sector_r[j * 256 + ((k0 + 128) & 255)], sector_r[j * 256 + ((k1 - (1 << j) + 1 + 128) & 255)]);
             return dmin2 <= (double)rmax * (double)rmax;
         }
         return true;

@@ -1028,7 +1028,7 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
         TRY(dev_alloc(&h->tile_shared, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_ctrl, 4));
         TRY(dev_alloc(&h->tile_dense, h->map_stride));
-        TRY(dev_alloc(&h->tile_sector, 256));
+        TRY(dev_alloc(&h->tile_sector, 256 * slamk::SECTOR_LEVELS));
         if (!rc)
         {
             // slam/mcl.cpp:30: every canvas is the blank tile 0 (128), nothing else is referenced
