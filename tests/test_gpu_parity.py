@@ -726,6 +726,37 @@ def test_tiled_pool_exhaustion_is_reported(sa):
 
 
 @pytest.mark.parametrize("storage", ["dense", "tiled"])
+def test_cell_counters_can_be_switched_off(sa, storage):
+    """slam_mcl_collect_stats(0): the two-phase kernel is compiled without its cell counters; weights, selection and
+    canvases are what they are with the counters, and stats() fails loudly instead of returning stale numbers."""
+    st = {"dense": sa.capi.MAPS_DENSE, "tiled": sa.capi.MAPS_TILED}[storage]
+    N, B, rows, cols = 200, 90, 500, 600
+    free = orc.load_map("map")
+    on = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=21, map_storage=st)
+    off = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=21, map_storage=st)
+    off.collect_stats(False)
+    pose = [300.0, 250.0, 0.3]
+    for step in range(3):
+        pose = [pose[0] + 2.5 * np.cos(pose[2]), pose[1] + 2.5 * np.sin(pose[2]), pose[2]]
+        ang, dist = orc.make_scan(free, pose, OFFSET, B)
+        for f in (on, off):
+            f.predict([0.0, 2.5, 0.0], [1e-3] * 4)
+            f.update(ang, dist, 5.0, 500.0, OFFSET)
+        assert_bits(on.weights(), off.weights(), f"step {step}: weights")
+        assert np.array_equal(on.last_indices(), off.last_indices())
+        for p in (0, N // 2, N - 1):
+            assert np.array_equal(on.map_of(p), off.map_of(p))
+    assert on.stats()["cells_read"] > 0
+    with pytest.raises(RuntimeError, match="switched off"):
+        off.stats()
+    off.collect_stats(True)
+    off.predict([0.0, 2.5, 0.0], [1e-3] * 4), on.predict([0.0, 2.5, 0.0], [1e-3] * 4)
+    off.update_weights(ang, dist, 5.0, 500.0, OFFSET), on.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+    assert off.stats() == on.stats()
+    on.close(), off.close()
+
+
+@pytest.mark.parametrize("storage", ["dense", "tiled"])
 def test_device_index_arrays_are_range_checked(sa, storage):
     """local_idx_dev / pos_dev live on the device: an entry out of range must not reach memory; it is
     skipped and reported by the call (synchronous handles) as an error."""
