@@ -1006,20 +1006,39 @@ __global__ void __launch_bounds__(256) k_tab_gather(const int32_t* tab, int32_t*
     }
 }
 
+// (four entries per thread, one 16-byte load: a thread per entry spent its time launching 700 000 workgroups)
 __global__ void __launch_bounds__(256) k_tile_shared(const int32_t* tab, int64_t total, const int* who, int* shared, int live)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= total) return;
-    const int id = tab[k];
-    if (id && who[id] != (int)k) shared[id] = live;
+    const int64_t k0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (k0 >= total) return;
+    int id[4] = {0, 0, 0, 0};
+    if (k0 + 4 <= total)
+    {
+        const int4 v = *reinterpret_cast<const int4*>(tab + k0);
+        id[0] = v.x, id[1] = v.y, id[2] = v.z, id[3] = v.w;
+    }
+    else
+        for (int u = 0; k0 + u < total; ++u) id[u] = tab[k0 + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (id[u] && who[id[u]] != (int)(k0 + u)) shared[id[u]] = live;
 }
 
 __global__ void __launch_bounds__(256) k_tile_own(int32_t* tab, int64_t total, const int* who, const int* shared, int live)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= total) return;
-    const int id = tab[k];
-    if (id && who[id] == (int)k && shared[id] != live) tab[k] = id | TILE_OWN;
+    const int64_t k0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (k0 >= total) return;
+    int id[4] = {0, 0, 0, 0};
+    if (k0 + 4 <= total)
+    {
+        const int4 v = *reinterpret_cast<const int4*>(tab + k0);
+        id[0] = v.x, id[1] = v.y, id[2] = v.z, id[3] = v.w;
+    }
+    else
+        for (int u = 0; k0 + u < total; ++u) id[u] = tab[k0 + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (id[u] && who[id[u]] == (int)(k0 + u) && shared[id[u]] != live) tab[k0 + u] = id[u] | TILE_OWN;
 }
 
 // free list = every tile but the blank one whose mark is not `live` (order irrelevant).  8192 ids per

@@ -266,9 +266,9 @@ int tile_collect(slam_mcl* h, const int32_t* src)
     hipLaunchKernelGGL(slamk::k_tab_gather, dim3((unsigned)h->n), dim3(256), 0, h->stream, h->tile_tab, h->tile_tab2, src,
                        h->tile_T, h->tile_ref, h->tile_who, live);
     std::swap(h->tile_tab, h->tile_tab2);
-    hipLaunchKernelGGL(slamk::k_tile_shared, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, total,
+    hipLaunchKernelGGL(slamk::k_tile_shared, dim3((unsigned)cdiv(total, 1024)), dim3(256), 0, h->stream, h->tile_tab, total,
                        h->tile_who, h->tile_shared, live);
-    hipLaunchKernelGGL(slamk::k_tile_own, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, h->tile_tab, total,
+    hipLaunchKernelGGL(slamk::k_tile_own, dim3((unsigned)cdiv(total, 1024)), dim3(256), 0, h->stream, h->tile_tab, total,
                        h->tile_who, h->tile_shared, live);
     hipLaunchKernelGGL(slamk::k_tile_free, dim3((unsigned)cdiv(h->tile_cap, 8192)), dim3(256), 0, h->stream, h->tile_ref,
                        live, (int)h->tile_cap, h->tile_free, h->tile_ctrl);
