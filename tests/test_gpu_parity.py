@@ -318,6 +318,9 @@ def test_cone_planes_built_on_the_device_equal_the_host_construction(sa):
     cases += [(59, 60, 0.03), (60, 124, 0.03), (61, 188, 0.01), (300, 63, 0.01), (1, 1, 0.0), (2, 700, 0.004), (700, 2, 0.004)]
     grids = [np.where(rng.random((int(r), int(c))) < d, 0, 255).astype(np.uint8) for r, c, d in cases]
     grids += [(orc.load_map("floor_plan") * 255).astype(np.uint8), (orc.load_map("maze") * 255).astype(np.uint8)]
+    from slam_amd import synth
+
+    grids.append(synth.make_grid(3000)[:2900, :])  # corridors and rooms of the synthetic benchmark grid, not square
     for g in grids:
         rows, cols = g.shape
         f = sa.Filter(8, rows, cols)
