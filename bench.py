@@ -177,6 +177,7 @@ def slam_entry(sa, capi, device, label, n, rows, cols, free, true0, pool, steps,
     t0 = time.perf_counter()
     for _ in range(steps):
         f.predict(odom, alphas); f.update(*scans[k], STDDEV, MAX_DIST, OFFSET); k += 1
+    host_ms = (time.perf_counter() - t0) / steps * 1e3  # time to ENQUEUE a step
     f.synchronize()
     ms_step = (time.perf_counter() - t0) / steps * 1e3
     # roofline of the walk kernel from the next steps, one at a time (the counters of a pass are read after it)
@@ -220,6 +221,7 @@ def slam_entry(sa, capi, device, label, n, rows, cols, free, true0, pool, steps,
                              "the particle's tile copies (4 KiB per tile its scan can write: they are no algorithmic bytes) and its walk "
                              "is instruction-issue bound (DESIGN.md): this fraction is reported, not claimed"},
         "kernel_ms_per_step": {g: v[0] / max(extra, 1) for g, v in kms.items()},
+        "host_enqueue_ms_per_step": host_ms,
         "tiles": tiles,
     }
     if with_cpu:
