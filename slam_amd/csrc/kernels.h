@@ -279,6 +279,42 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     if (DIRECT && real) a.w[p] = a.log_domain ? acc : dm_exp(acc);
 }
 
+// The cloud's bounding box from its first 256 particles into box[which] (see k_order_keys): launched before the first
+// weighting pass after the poses were set or seeded, so that even that pass is ordered for the cloud it meets.
+__global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, const double* y, int* box, int which)
+{
+    __shared__ int part[4][4];
+    const int64_t p = threadIdx.x;
+    int lx = 0x7fffffff, ly = 0x7fffffff, hx = -0x7fffffff - 1, hy = -0x7fffffff - 1;
+    if (p < n)
+    {
+        lx = hx = slam_f2i(x[p]);
+        ly = hy = slam_f2i(y[p]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        lx = min(lx, __shfl_xor(lx, o));
+        ly = min(ly, __shfl_xor(ly, o));
+        hx = max(hx, __shfl_xor(hx, o));
+        hy = max(hy, __shfl_xor(hy, o));
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        int* q = part[threadIdx.x >> 6];
+        q[0] = lx, q[1] = ly, q[2] = hx, q[3] = hy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        int* cur = box + 4 * which;
+        cur[0] = min(min(part[0][0], part[1][0]), min(part[2][0], part[3][0]));
+        cur[1] = min(min(part[0][1], part[1][1]), min(part[2][1], part[3][1]));
+        cur[2] = max(max(part[0][2], part[1][2]), max(part[2][2], part[3][2]));
+        cur[3] = max(max(part[0][3], part[1][3]), max(part[2][3], part[3][3]));
+    }
+}
+
 // Pose-coherent order for k_rays_pl.  The weight of a particle does not depend on which lane
 // computes it, so the particles are dealt to wavefronts by a key of (heading bucket, 4-cell tile):
 // the 64 rays a wavefront walks together then start from the same few cells with headings within
@@ -287,7 +323,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
 __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, const double* y, const double* th,
                                                     int mode, int key_bits, uint32_t* keys, int32_t* ident,
                                                     unsigned long long* stats, const double* scan_src, double* scan_dst,
-                                                    int scan_n)
+                                                    int scan_n, int* box, int pass_no, int wide_mode)
 {
     // side job of the last workgroup: the new scan from its pinned host slot to the device (read by the kernels that
     // follow on the stream; saves the copy kernel and its launch gap)
@@ -310,24 +346,71 @@ __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, 
             }
         }
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // The cloud's extent chooses the order (wide_mode != 0): `box` holds two bounding boxes {xmin, ymin, xmax, ymax} in
+    // cells; this pass reads the one the pass before it wrote and workgroup 0 writes the other from its 256 particles (a
+    // sample: the particle order is the weight order, which knows nothing of place; no atomics: 1563 wavefronts updating
+    // one cache line cost 110 us; no launch, no host round trip; the choice lags the cloud by one step, which an
+    // ordering heuristic may).  Heading first is best while the part of the planes the cloud can reach stays in the
+    // caches; a cloud spread over more than 2^22 cells (eight planes: 32 MB = all L2) is ordered by place first: the
+    // wavefronts in flight then work on one band of the map (the 16384^2 shard of bench.py: 2.05 TB of HBM reads per
+    // pass and 297 ms with the heading first, 115 ms with the place first).
+    if (wide_mode)
+    {
+        const int* prev = box + 4 * ((pass_no + 1) & 1);
+        const int bx0 = prev[0], by0 = prev[1], bx1 = prev[2], by1 = prev[3];
+        if (bx1 >= bx0 && by1 >= by0 && ((double)bx1 - bx0 + 1.0) * ((double)by1 - by0 + 1.0) > 4194304.0) mode = wide_mode;
+        if (blockIdx.x == 0)
+        {
+            __shared__ int part[4][4];
+            int lx = 0x7fffffff, ly = 0x7fffffff, hx = -0x7fffffff - 1, hy = -0x7fffffff - 1;
+            if (p < n)
+            {
+                lx = hx = slam_f2i(x[p]);
+                ly = hy = slam_f2i(y[p]);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1)
+            {
+                lx = min(lx, __shfl_xor(lx, o));
+                ly = min(ly, __shfl_xor(ly, o));
+                hx = max(hx, __shfl_xor(hx, o));
+                hy = max(hy, __shfl_xor(hy, o));
+            }
+            if ((threadIdx.x & 63) == 0)
+            {
+                int* q = part[threadIdx.x >> 6];
+                q[0] = lx, q[1] = ly, q[2] = hx, q[3] = hy;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0)
+            {
+                int* cur = box + 4 * (pass_no & 1);
+                cur[0] = min(min(part[0][0], part[1][0]), min(part[2][0], part[3][0]));
+                cur[1] = min(min(part[0][1], part[1][1]), min(part[2][1], part[3][1]));
+                cur[2] = max(max(part[0][2], part[1][2]), max(part[2][2], part[3][2]));
+                cur[3] = max(max(part[0][3], part[1][3]), max(part[2][3], part[3][3]));
+            }
+        }
+    }
     if (p >= n) return;
     if (p < 3) stats[p] = 0;  // the pass's counters start at zero (saves a memset launch)
     // mode = kind | (tile_shift + 1) << 4 | heading_bits << 8 (0 fields: 4-cell tiles, 10 heading bits:
     // best for a converged cloud, 4 % over 2-cell tiles / 8 bits; a wide cloud prefers coarser headings)
     const int kind = mode & 15;
     const int tshift = ((mode >> 4) & 15) ? ((mode >> 4) & 15) - 1 : 2;
-    const int tbits = (mode >> 8) ? (mode >> 8) : 10;
+    const int tbits = ((mode >> 8) & 15) ? ((mode >> 8) & 15) : 10;
+    const int tshift_y = ((mode >> 12) & 15) ? ((mode >> 12) & 15) - 1 : tshift;  // (tiles may be wider than tall: a cache line runs along x)
     const int nb = (key_bits - tbits) >> 1;  // tile bits per axis; the key has tbits + 2 nb <= key_bits bits
     const unsigned tmask = (1u << nb) - 1u;
     const unsigned tx = ((unsigned)slam_f2i(x[p]) >> tshift) & tmask;
-    const unsigned ty = ((unsigned)slam_f2i(y[p]) >> tshift) & tmask;
+    const unsigned ty = ((unsigned)slam_f2i(y[p]) >> tshift_y) & tmask;
     // heading in turns; 1/(2 pi) to double precision is plenty for a bucket index
     const unsigned tb = (unsigned)slam_f2i((th[p] * 0.15915494309189535 + 4.0) * (double)(1u << tbits)) & ((1u << tbits) - 1u);
     unsigned k;
     if (kind == 2)
         k = (ty << (nb + tbits)) | (tx << tbits) | tb;
-    else if (kind == 3)
-    {  // Morton order of the tiles below the heading bucket
+    else if (kind == 3 || kind == 4)
+    {  // Morton order of the tiles below the heading bucket (3) or above it (4: place first, for clouds wider than the caches)
         unsigned a = tx, b = ty;
         a = (a | (a << 8)) & 0x00ff00ffu;
         a = (a | (a << 4)) & 0x0f0f0f0fu;
@@ -337,7 +420,7 @@ __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, 
         b = (b | (b << 4)) & 0x0f0f0f0fu;
         b = (b | (b << 2)) & 0x33333333u;
         b = (b | (b << 1)) & 0x55555555u;
-        k = (tb << (2 * nb)) | (a | (b << 1));
+        k = kind == 3 ? (tb << (2 * nb)) | (a | (b << 1)) : ((a | (b << 1)) << tbits) | tb;
     }
     else
         k = (tb << (2 * nb)) | (ty << nb) | tx;

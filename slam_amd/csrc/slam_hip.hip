@@ -147,6 +147,9 @@ struct slam_mcl
     double* lw = nullptr;  // scratch of the particle-lane weight kernels
     size_t lw_cap = 0;     // doubles
     uint32_t *okeys = nullptr, *okeys2 = nullptr;  // pose-coherent order of the particle-lane kernels
+    int* obox = nullptr;                            // ... two bounding boxes of the cloud (k_order_keys)
+    int order_pass = 0;
+    bool poses_reset = true;  // set_poses / seed_* since the last weighting pass
     int32_t *oident = nullptr, *order = nullptr;
     void* osort_tmp = nullptr;
     size_t osort_tmp_bytes = 0;
@@ -239,6 +242,7 @@ struct Tuning
     int fast_div;    // SLAM_FAST_DIV: 1 = the particle-lane kernel forms xarg / stddev from the reciprocal (same bits), 0 = divides
     int clamp_limit; // SLAM_RAY_CLAMP_LIMIT: 1 = the localization hit search stops beyond z + 4 sigma (default), 0 = always to max_dist
     int cone_build;  // SLAM_CONE_BUILD: 1 = the cone-clearance planes are built on the device (default), 0 = on the host
+    int order_wide;  // SLAM_PL_ORDER_WIDE: order mode for a cloud spread over more than 2^22 cells (0 = never switch)
     int tile_fuse;   // SLAM_TILE_FUSE: 1 = the two-phase kernel makes the planned tile copies itself (default), 0 = k_tile_copy before it
 };
 const Tuning& tuning()
@@ -249,7 +253,7 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_TILE_FUSE", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 2 | (5 << 4) | (6 << 8)), env_int("SLAM_TILE_FUSE", 1)};
     return t;
 }
 
@@ -587,6 +591,12 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             if (!h->okeys)
             {
                 int rc;
+                if ((rc = dev_alloc(&h->obox, 8))) return rc;
+                {  // both boxes empty (max < min): the first pass keeps the default order
+                    const int empty[8] = {0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1,
+                                          0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1};
+                    HIPCHK(hipMemcpy(h->obox, empty, sizeof(empty), hipMemcpyHostToDevice));
+                }
                 if ((rc = dev_alloc(&h->okeys, h->n)) || (rc = dev_alloc(&h->okeys2, h->n)) ||
                     (rc = dev_alloc(&h->oident, h->n)) || (rc = dev_alloc(&h->order, h->n)))
                     return rc;
@@ -598,9 +608,15 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 h->osort_tmp = tmp;
                 h->osort_tmp_bytes = bytes;
             }
+            if (h->poses_reset)
+            {  // poses set or seeded since the last pass: the box this pass reads comes from the new cloud
+                hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, (h->order_pass + 1) & 1);
+                h->poses_reset = false;
+            }
             hipExtLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, ext.a, nullptr, 0, h->n,
                                   h->x, h->y, h->th, order_mode, order_bits, h->okeys, h->oident, h->stats, h->scan_pending,
-                                  h->scan_dev, (int)(h->scan_pending ? h->scan_pending_n : 0));
+                                  h->scan_dev, (int)(h->scan_pending ? h->scan_pending_n : 0), h->obox, h->order_pass++ & 1,
+                                  order_bits == 32 ? tuning().order_wide : 0);
             ext_started = true;
             if (h->scan_pending)
             {
@@ -860,7 +876,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
                     h->grid,  h->clr,    h->maps, h->maps2,    h->luts,         h->scan_dev,
                     h->inj_normals, h->inj_uniforms, h->idx, h->perm, h->slots, h->src,   h->keys, h->keys2,
                     h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
-                    h->okeys, h->okeys2, h->oident, h->order, h->osort_tmp, h->ss_tmp, h->wlin, h->wmax,
+                    h->okeys, h->okeys2, h->obox, h->oident, h->order, h->osort_tmp, h->ss_tmp, h->wlin, h->wmax,
                     h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_who, h->tile_shared, h->tile_ctrl, h->tile_dense, h->tile_sector,
                     h->tile_wl_p, h->tile_wl_t, h->tile_rng, h->pack_stamp, h->pack_ctr, h->pack_slot, h->dev_bad};
     for (void* p : ptrs)
@@ -1132,6 +1148,7 @@ SLAM_API int slam_mcl_set_poses(slam_mcl* h, const double* x, const double* y, c
 {
     int rc = check_handle(h);
     if (rc) return rc;
+    h->poses_reset = true;
     if (!x || !y || !theta || first < 0 || count < 0 || first + count > h->n) return fail(SLAM_ERR_ARG, "set_poses: bad range");
     for (int64_t k = 0; k < count; ++k)
         if (!std::isfinite(x[k]) || !std::isfinite(y[k]) || !std::isfinite(theta[k]))
@@ -1162,6 +1179,7 @@ SLAM_API int slam_mcl_seed_gaussian(slam_mcl* h, const double mean[3], const dou
 {
     int rc = check_handle(h);
     if (rc) return rc;
+    h->poses_reset = true;
     if (!mean || !sigma) return fail(SLAM_ERR_ARG, "seed_gaussian: null");
     for (int k = 0; k < 3; ++k)
         if (!std::isfinite(mean[k]) || !std::isfinite(sigma[k]) || sigma[k] < 0) return fail(SLAM_ERR_ARG, "seed_gaussian: bad value");
@@ -1175,6 +1193,7 @@ SLAM_API int slam_mcl_seed_uniform_free(slam_mcl* h)
 {
     int rc = check_handle(h);
     if (rc) return rc;
+    h->poses_reset = true;
     if (h->prm.mode != SLAM_MODE_LOCALIZATION || !h->have_map)
         return fail(SLAM_ERR_STATE, "seed_uniform_free needs localization mode and a map");
     hipLaunchKernelGGL(slamk::k_seed_uniform_free, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->y,

@@ -1342,7 +1342,13 @@ def test_full_shard_sizes_of_configs_3_and_5(sa, size, N, B, zmax, uniform):
     osub = sub[:24]
     olw, _ = orc.update_weights(x[osub], y[osub], th[osub], g, ang, dist, 0.5, zmax, OFFSET, math=orc.DET, log_domain=True)
     assert_bits(lw[osub], olw, "subset vs oracle")
+    # the second pass knows the cloud's extent (k_order_keys): the uniform cloud over 16384^2 is then dealt to the
+    # wavefronts by place first, the Gaussian one stays with the heading first: same bits either way
+    f.synchronize()
+    t0 = time.perf_counter()
     f.update_weights(ang, dist, 0.5, zmax, OFFSET)
+    f.synchronize()
+    print(f"second pass {(time.perf_counter() - t0) * 1e3:.1f} ms")
     assert_bits(f.weights(), lw, "idempotence")
     f.resample()
     P, total = f.prefix()
