@@ -283,6 +283,9 @@ def localization_shard_entry(sa, capi, device, label, size, n, B, zmax, uniform,
     return {
         "workload": label, "value": n * B / (ms_step * 1e-3), "unit": "particle-beams/s", "ms_per_step": ms_step, "steps": steps,
         "dtype": "f64", "step": "predict + weighting pass (no resample: the seeded cloud stays wide)",
+        "scan": {"range_mean": float(dist.mean()), "range_median": float(np.median(dist)), "beams_at_max_dist": int((dist >= zmax).sum()),
+                 "note": "the cost of a pass on a wide cloud depends on the scan: a particle's search ends at its hit or at z + 4 sigma; "
+                         "scans from open places of the same grid are up to 5x slower (DESIGN.md, tools/uniform_time.py)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "weighting pass (k_order_keys + sort + k_rays_pl [+ k_sum_lw])", "kernel_avg_ms": w_ms,
                      "algorithmic_bytes_per_launch": alg, "cells_per_ray_reference_walk": sbar,
