@@ -238,16 +238,15 @@ def localization_shard_entry(sa, capi, device, label, size, n, B, zmax, uniform,
 
     g = synth.make_grid(size)
     free01 = (g >= 128).astype(np.uint8)
-    free_cells = np.argwhere(g[size // 4:size // 4 + 64, size // 4:size // 4 + 2000] >= 128)
-    ci, cj = free_cells[len(free_cells) // 2]
-    true = [float(cj + size // 4) + 0.5, float(size - 1 - (ci + size // 4)) + 0.5, 0.7]
+    true = synth.open_pose(g)  # (until late in round 2 the 16384^2 sensor stood inside a wall: every beam measured 0.5 cells)
     sensor = sa.MCL.sensor_position(sa.Pose(*true), sa.Pose(*OFFSET))
     gm = sa.GridMap(free01, device=device)
     hits = gm.fake_lidar_scan([sensor.x, sensor.y, sensor.theta], 0.0, 2 * np.pi, zmax, B)[0]
     gm.close()
     ang = np.arange(B) * (2 * np.pi / B) - np.pi
     dist = np.where(hits[:, 0] != -1, np.hypot(hits[:, 1] - sensor.y, hits[:, 0] - sensor.x), zmax)
-    f = sa.Filter(n, size, size, device=device, seed=SEED, sort=capi.SORT_NONE, weight_domain=capi.WEIGHT_LOG, async_launch=True)
+    f = sa.Filter(n, size, size, device=device, seed=SEED, sort=capi.SORT_NONE, weight_domain=capi.WEIGHT_LOG, async_launch=True,
+                  raycaster=int(os.environ.get("BENCH_LOC_RAYCASTER", capi.RAYCAST_FAST)))  # experiments: 2 = wave per particle
     f.set_map(g)
     if uniform:
         f.seed_uniform_free()

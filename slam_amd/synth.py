@@ -41,3 +41,20 @@ def make_grid(size, seed=None, target_occupied=0.10, wall=3):
     g[:wall, :] = g[-wall:, :] = 0
     g[:, :wall] = g[:, -wall:] = 0
     return g
+
+
+def open_pose(g, margin=48, theta=0.7):
+    """A pose [x, y, theta] (world frame: x = column, y = rows - 1 - row) in the upper left quarter of the grid whose
+    surroundings are free for `margin` cells in every direction, so that a sensor mounted up to that far from the pose
+    (bench.py's offset is 30) still stands in free space and the scan taken there has real ranges.  (Round 2's first
+    choice, the middle free cell of a strip, put the 16384^2 sensor into a wall: every beam measured half a cell.)"""
+    size = g.shape[0]
+    free = (g >= 128)
+    step = 2 * margin + 1
+    i0 = size // 4
+    for i in range(i0, size - step, step):
+        for j in range(i0, size - step, step):
+            if free[i:i + step, j:j + step].all():
+                ci, cj = i + margin, j + margin
+                return [float(cj) + 0.5, float(size - 1 - ci) + 0.5, theta]
+    raise ValueError("no open place found")

@@ -1307,9 +1307,7 @@ def test_full_shard_sizes_of_configs_3_and_5(sa, size, N, B, zmax, uniform):
     g = synth.make_grid(size)
     free01 = (g >= 128).astype(np.uint8)
     rng = np.random.default_rng(size + 1)
-    free_cells = np.argwhere(g[size // 4:size // 4 + 64, size // 4:size // 4 + 2000] >= 128)
-    ci, cj = free_cells[len(free_cells) // 2]
-    true = [float(cj + size // 4) + 0.5, float(size - 1 - (ci + size // 4)) + 0.5, 0.7]
+    true = synth.open_pose(g)
     lib = sa.capi.load_library()
     sensor = orc.sensor_position(true, OFFSET, orc.DET)
     hits = np.empty((B, 2))
