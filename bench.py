@@ -279,6 +279,14 @@ def localization_shard_entry(sa, capi, device, label, size, n, B, zmax, uniform,
     w_ms = kms["weights"][0] / max(kms["weights"][1], 1)
     alg = n * B * sbar + 40.0 * n + 16.0 * B
     achieved = alg / (w_ms * 1e-3) / 1e9
+    traffic = None
+    if size == 16384:  # the counter passes of profiles/run_profile.sh cover this entry; quoted while the sources are unchanged
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_weights_kernel.json")))
+            if rec.get("source_fingerprint") == source_fingerprint():
+                traffic = rec["kernels"]["k_rays_pl (16384^2 shard, 12.5 M particles)"]["hbm_bytes"]
+        except Exception:
+            traffic = None
     return {
         "workload": label, "value": n * B / (ms_step * 1e-3), "unit": "particle-beams/s", "ms_per_step": ms_step, "steps": steps,
         "dtype": "f64", "step": "predict + weighting pass (no resample: the seeded cloud stays wide)",
@@ -286,7 +294,7 @@ def localization_shard_entry(sa, capi, device, label, size, n, B, zmax, uniform,
                  "note": "the cost of a pass on a wide cloud depends on the scan: a particle's search ends at its hit or at z + 4 sigma; "
                          "scans from open places of the same grid are up to 5x slower (DESIGN.md, tools/uniform_time.py)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "weighting pass (k_order_keys + sort + k_rays_pl [+ k_sum_lw])", "kernel_avg_ms": w_ms,
+                     "traffic": traffic, "kernel": "weighting pass (k_order_keys + sort + k_rays_pl [+ k_sum_lw])", "kernel_avg_ms": w_ms,
                      "algorithmic_bytes_per_launch": alg, "cells_per_ray_reference_walk": sbar,
                      "note": "algorithmic, reference-equivalent bytes (cells the reference's walk reads, from 4096 particles on the "
                              "cell-by-cell kernel); the clearance search reads far fewer"},

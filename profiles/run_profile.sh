@@ -8,9 +8,9 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-# counter passes: the headline configuration plus the 125 000-particle grid-SLAM shard (k_weights_S2)
-export BENCH_SECONDARY=${BENCH_SECONDARY_PMC:-slam125k}
-BENCH="python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+# counter passes: the headline configuration plus the 125 000-particle grid-SLAM shard (k_weights_S2) and the 16384^2 shard
+export BENCH_SECONDARY=${BENCH_SECONDARY_PMC:-slam125k,loc16384}
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 # trace pass 1: the headline alone, bench.py defaults (5 warm-up + 20 timed steps, then 20 more steps with every kernel group
 # bracketed by events for kernel_ms_per_step): the same command the bench line comes from, minus the secondary entries
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- python3 $REPO/bench.py --no-cpu-baseline --no-secondary > "$OUT/trace.log" 2>&1 || exit 1

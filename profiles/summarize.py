@@ -53,7 +53,7 @@ def slam_summary(base, tag):
     """profiles/rocprof_<tag>_slam.txt: the grid-SLAM kernels of the 125 000-particle entry (the launches of
     k_weights_S2 with the largest grid, and every tile kernel between the first and the last of them)."""
     lines = [f"# rocprofv3 summary of the grid-SLAM kernels, tag {tag} (profiles/run_profile.sh: trace pass 2 = bench.py --no-cpu-baseline with all",
-             "# secondary entries; counter passes = bench.py --steps 10 --warmup 3 --no-cpu-baseline with BENCH_SECONDARY=slam125k).",
+             "# secondary entries; counter passes = bench.py --steps 5 --warmup 2 --no-cpu-baseline with BENCH_SECONDARY=slam125k).",
              "# 125 000 particles x 90 beams, 2354x2464 canvases as copy-on-write tiles, maze scans (bench.py slam_entry)."]
     t = glob.glob(os.path.join(base, "trace_sec", "*_results.db"))
     if t:
@@ -120,14 +120,15 @@ def weights_traffic(base):
     if not f or not w:
         return None
     out = {"source": "profiles/rocprof_%s.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                     "bench.py --steps 10 --warmup 3 --no-cpu-baseline, BENCH_SECONDARY=slam125k)" % os.path.basename(base).replace("prof_", ""),
+                     "bench.py --steps 5 --warmup 2 --no-cpu-baseline, BENCH_SECONDARY=slam125k)" % os.path.basename(base).replace("prof_", ""),
            "units": "FETCH_SIZE and WRITE_SIZE are KB per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes "
                     "for gfx950 (it tallies 128-B requests at 64 B); byte-gather reads of k_rays_pl are an uncalibrated "
                     "access width",
            "kernels": {}}
     total = 0.0
     for k in ("k_rays_pl", "k_sum_lw"):
-        fk, wk = avg(f[0], "FETCH_SIZE", f"%{k}%"), avg(w[0], "WRITE_SIZE", f"%{k}%")
+        like = "%k_rays_pl<5, false, false>%" if k == "k_rays_pl" else f"%{k}%"  # (not the slab-less variant of the large shards)
+        fk, wk = avg(f[0], "FETCH_SIZE", like), avg(w[0], "WRITE_SIZE", like)
         if fk is None or wk is None:
             return None
         b = 2.0 * fk * 1024.0 + wk * 1024.0
@@ -139,6 +140,17 @@ def weights_traffic(base):
     if fk is not None and wk is not None:
         out["kernels"]["k_weights_S2 (125 000-particle shard)"] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
                                                                    "hbm_bytes": 2.0 * fk * 1024.0 + wk * 1024.0}
+    # the ray kernel of the 16384^2 shard (12.5 M particles: the launches of k_rays_pl with the largest grid)
+    def avg_big(db, counter):
+        cur = sqlite3.connect(db).cursor()
+        big = cur.execute("select max(grid_size) from counters_collection where kernel_name like '%k_rays_pl%'").fetchone()[0]
+        r = cur.execute("select avg(value) from counters_collection where counter_name=? and kernel_name like '%k_rays_pl%' and grid_size=?",
+                        (counter, big)).fetchone()
+        return (float(r[0]) if r and r[0] is not None else None), big
+    (fk, big), (wk, _) = avg_big(f[0], "FETCH_SIZE"), avg_big(w[0], "WRITE_SIZE")
+    if fk is not None and wk is not None and big and big > 5_000_000:
+        out["kernels"]["k_rays_pl (16384^2 shard, 12.5 M particles)"] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
+                                                                         "hbm_bytes": 2.0 * fk * 1024.0 + wk * 1024.0}
     # bench.py quotes hbm_bytes_per_launch only while the kernel sources are the ones measured here
     import hashlib
     h = hashlib.sha256()
