@@ -281,7 +281,9 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
 
 // The cloud's bounding box from its first 256 particles into box[which] (see k_order_keys): launched before the first
 // weighting pass after the poses were set or seeded, so that even that pass is ordered for the cloud it meets.
-__global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, const double* y, int* box, int which)
+// box_host: the same four numbers in pinned host memory (a store over PCIe, nobody waits for it): the host reads them
+// some passes later to choose the kernel SHAPE for the cloud (do_weights).
+__global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, const double* y, int* box, int which, int* box_host)
 {
     __shared__ int part[4][4];
     const int64_t p = threadIdx.x;
@@ -312,6 +314,8 @@ __global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, c
         cur[1] = min(min(part[0][1], part[1][1]), min(part[2][1], part[3][1]));
         cur[2] = max(max(part[0][2], part[1][2]), max(part[2][2], part[3][2]));
         cur[3] = max(max(part[0][3], part[1][3]), max(part[2][3], part[3][3]));
+        if (box_host)
+            for (int k = 0; k < 4; ++k) box_host[k] = cur[k];
     }
 }
 
@@ -323,7 +327,7 @@ __global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, c
 __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, const double* y, const double* th,
                                                     int mode, int key_bits, uint32_t* keys, int32_t* ident,
                                                     unsigned long long* stats, const double* scan_src, double* scan_dst,
-                                                    int scan_n, int* box, int pass_no, int wide_mode)
+                                                    int scan_n, int* box, int pass_no, int wide_mode, int* box_host)
 {
     // side job of the last workgroup: the new scan from its pinned host slot to the device (read by the kernels that
     // follow on the stream; saves the copy kernel and its launch gap)
@@ -389,6 +393,8 @@ __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, 
                 cur[1] = min(min(part[0][1], part[1][1]), min(part[2][1], part[3][1]));
                 cur[2] = max(max(part[0][2], part[1][2]), max(part[2][2], part[3][2]));
                 cur[3] = max(max(part[0][3], part[1][3]), max(part[2][3], part[3][3]));
+                if (box_host)  // (see k_order_box)
+                    for (int k = 0; k < 4; ++k) box_host[k] = cur[k];
             }
         }
     }

@@ -148,6 +148,7 @@ struct slam_mcl
     size_t lw_cap = 0;     // doubles
     uint32_t *okeys = nullptr, *okeys2 = nullptr;  // pose-coherent order of the particle-lane kernels
     int* obox = nullptr;                            // ... two bounding boxes of the cloud (k_order_keys)
+    int* obox_host = nullptr;                       // ... and the latest one in pinned host memory (kernel shape, do_weights)
     int order_pass = 0;
     bool poses_reset = true;  // set_poses / seed_* since the last weighting pass
     int32_t *oident = nullptr, *order = nullptr;
@@ -243,6 +244,7 @@ struct Tuning
     int clamp_limit; // SLAM_RAY_CLAMP_LIMIT: 1 = the localization hit search stops beyond z + 4 sigma (default), 0 = always to max_dist
     int cone_build;  // SLAM_CONE_BUILD: 1 = the cone-clearance planes are built on the device (default), 0 = on the host
     int order_wide;  // SLAM_PL_ORDER_WIDE: order mode for a cloud spread over more than 2^22 cells (0 = never switch)
+    int beam_cells;  // SLAM_BEAM_CELLS: cells of the cloud's bounding box per particle above which the wave-per-particle kernel runs (0 = never)
     int tile_fuse;   // SLAM_TILE_FUSE: 1 = the two-phase kernel makes the planned tile copies itself (default), 0 = k_tile_copy before it
 };
 const Tuning& tuning()
@@ -253,12 +255,26 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 2 | (5 << 4) | (6 << 8)), env_int("SLAM_TILE_FUSE", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 2 | (5 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1)};
     return t;
 }
 
 // The sample sort serves the sizes at which rocPRIM's sort is a chain of launch-bound merge passes.
 bool use_sample_sort(const slam_mcl* h, int which) { return h->ss_tmp && (tuning().sort_impl & which) && h->n >= sortk::MIN_N && h->n <= sortk::MAX_N; }
+
+// The cloud's bounding boxes (k_order_keys / k_order_box): two on the device, the latest one also in pinned host memory.
+int ensure_order_box(slam_mcl* h)
+{
+    if (h->obox) return SLAM_OK;
+    int rc;
+    if ((rc = dev_alloc(&h->obox, 8))) return rc;
+    // both boxes empty (max < min): the first pass keeps the default order and the default kernel shape
+    const int empty[8] = {0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1, 0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1};
+    HIPCHK(hipMemcpy(h->obox, empty, sizeof(empty), hipMemcpyHostToDevice));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->obox_host), 4 * sizeof(int), hipHostMallocDefault));
+    for (int k = 0; k < 4; ++k) h->obox_host[k] = empty[k];
+    return SLAM_OK;
+}
 
 // SLAM_MAPS_TILED: new tables (src != nullptr: table p = old table src[p]), census of the tiles (who
 // owns what, exactly), free list of the unreferenced ones, allocation cursor restarted.
@@ -442,9 +458,20 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.stats = h->stats;
     a.luts = h->luts;
     const int order_mode = tuning().order_mode;
+    // A cloud so sparse that no two particles are neighbours (more than SLAM_BEAM_CELLS cells of its bounding box per
+    // particle: a uniformly seeded one) gains nothing from lanes over particles: the wave-per-particle kernel, whose
+    // lanes are consecutive beams of ONE particle, is 1.1-1.6x faster there (and 2.2x slower on a dense cloud).  The box
+    // is the one a kernel of an earlier pass left in pinned host memory: no wait, a pass or two late.
+    bool sparse_cloud = false;
+    if (!slam_mode && h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096 && h->obox_host && tuning().beam_cells > 0)
+    {
+        const volatile int* bx = h->obox_host;
+        const int x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
+        if (x1 >= x0 && y1 >= y0) sparse_cloud = ((double)x1 - x0 + 1.0) * ((double)y1 - y0 + 1.0) > (double)tuning().beam_cells * (double)h->n;
+    }
     const bool particle_lanes = !slam_mode && (h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES ||
                                                h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT ||
-                                               (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096));
+                                               (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096 && !sparse_cloud));
     if (!(particle_lanes && order_mode > 0 && h->n >= 3))  // k_order_keys zeroes the counters itself
         HIPCHK(hipMemsetAsync(h->stats, 0, 3 * sizeof(unsigned long long), h->stream));
     if (!(particle_lanes && order_mode > 0 && tuning().scan_fuse))  // k_order_keys also brings the new scan to scan_dev
@@ -591,12 +618,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             if (!h->okeys)
             {
                 int rc;
-                if ((rc = dev_alloc(&h->obox, 8))) return rc;
-                {  // both boxes empty (max < min): the first pass keeps the default order
-                    const int empty[8] = {0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1,
-                                          0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1};
-                    HIPCHK(hipMemcpy(h->obox, empty, sizeof(empty), hipMemcpyHostToDevice));
-                }
+                if ((rc = ensure_order_box(h))) return rc;
                 if ((rc = dev_alloc(&h->okeys, h->n)) || (rc = dev_alloc(&h->okeys2, h->n)) ||
                     (rc = dev_alloc(&h->oident, h->n)) || (rc = dev_alloc(&h->order, h->n)))
                     return rc;
@@ -610,13 +632,13 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             }
             if (h->poses_reset)
             {  // poses set or seeded since the last pass: the box this pass reads comes from the new cloud
-                hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, (h->order_pass + 1) & 1);
+                hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, (h->order_pass + 1) & 1, h->obox_host);
                 h->poses_reset = false;
             }
             hipExtLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, ext.a, nullptr, 0, h->n,
                                   h->x, h->y, h->th, order_mode, order_bits, h->okeys, h->oident, h->stats, h->scan_pending,
                                   h->scan_dev, (int)(h->scan_pending ? h->scan_pending_n : 0), h->obox, h->order_pass++ & 1,
-                                  order_bits == 32 ? tuning().order_wide : 0);
+                                  order_bits == 32 ? tuning().order_wide : 0, h->obox_host);
             ext_started = true;
             if (h->scan_pending)
             {
@@ -678,6 +700,11 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     {
         a.grid = h->clr;
         a.map_stride = h->clr_stride;
+        if (sparse_cloud)
+        {  // (k_order_keys does not run on this path: the box of this pass from a launch of its own)
+            hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, h->order_pass++ & 1, h->obox_host);
+            h->poses_reset = false;
+        }
         hipLaunchKernelGGL(slamk::k_weights_L<0>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
     }
     else
@@ -883,6 +910,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
         if (p) hipFree(p);
     for (int k = 0; k < slam_mcl::SCAN_RING; ++k)
         if (h->scan_pin[k]) hipHostFree(h->scan_pin[k]);
+    if (h->obox_host) hipHostFree(h->obox_host);
     for (int g = 0; g < slam_mcl::SCAN_RING / slam_mcl::SCAN_GROUP; ++g)
         if (h->scan_ev[g]) hipEventDestroy(h->scan_ev[g]);
     for (size_t l = 0; l < h->lvl_s.size(); ++l)
