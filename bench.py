@@ -284,7 +284,7 @@ def localization_shard_entry(sa, capi, device, label, size, n, B, zmax, uniform,
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_weights_kernel.json")))
             if rec.get("source_fingerprint") == source_fingerprint():
-                traffic = rec["kernels"]["k_rays_pl (16384^2 shard, 12.5 M particles)"]["hbm_bytes"]
+                traffic = rec["kernels"]["weighting kernel of the 16384^2 shard (k_weights_L<0>, 12.5 M particles)"]["hbm_bytes"]
         except Exception:
             traffic = None
     return {

@@ -140,17 +140,20 @@ def weights_traffic(base):
     if fk is not None and wk is not None:
         out["kernels"]["k_weights_S2 (125 000-particle shard)"] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
                                                                    "hbm_bytes": 2.0 * fk * 1024.0 + wk * 1024.0}
-    # the ray kernel of the 16384^2 shard (12.5 M particles: the launches of k_rays_pl with the largest grid)
-    def avg_big(db, counter):
+    # the weighting kernel of the 16384^2 shard (12.5 M particles; its sparse cloud gets the wave-per-particle kernel
+    # k_weights_L<0> from the second pass on): the launches with the largest grid
+    def avg_big(db, counter, like):
         cur = sqlite3.connect(db).cursor()
-        big = cur.execute("select max(grid_size) from counters_collection where kernel_name like '%k_rays_pl%'").fetchone()[0]
-        r = cur.execute("select avg(value) from counters_collection where counter_name=? and kernel_name like '%k_rays_pl%' and grid_size=?",
-                        (counter, big)).fetchone()
+        big = cur.execute("select max(grid_size) from counters_collection where kernel_name like ?", (like,)).fetchone()[0]
+        if not big:
+            return None, None
+        r = cur.execute("select avg(value) from counters_collection where counter_name=? and kernel_name like ? and grid_size=?",
+                        (counter, like, big)).fetchone()
         return (float(r[0]) if r and r[0] is not None else None), big
-    (fk, big), (wk, _) = avg_big(f[0], "FETCH_SIZE"), avg_big(w[0], "WRITE_SIZE")
-    if fk is not None and wk is not None and big and big > 5_000_000:
-        out["kernels"]["k_rays_pl (16384^2 shard, 12.5 M particles)"] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
-                                                                         "hbm_bytes": 2.0 * fk * 1024.0 + wk * 1024.0}
+    (fk, big), (wk, _) = avg_big(f[0], "FETCH_SIZE", "%k_weights_L<0>%"), avg_big(w[0], "WRITE_SIZE", "%k_weights_L<0>%")
+    if fk is not None and wk is not None and big and big > 100_000_000:
+        out["kernels"]["weighting kernel of the 16384^2 shard (k_weights_L<0>, 12.5 M particles)"] = {
+            "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes": 2.0 * fk * 1024.0 + wk * 1024.0}
     # bench.py quotes hbm_bytes_per_launch only while the kernel sources are the ones measured here
     import hashlib
     h = hashlib.sha256()
