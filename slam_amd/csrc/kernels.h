@@ -165,6 +165,17 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
     const double sy = py + s0 * a.sd;
     double acc = 0.0;
     slam_ray_stats st = {0, 0, 0};
+    // the same for every beam of the particle (as in k_rays_pl): the prepared start coordinates and the start cell
+    slam_axis_pre PX, PY;
+    int i0 = 0, j0 = 0;
+    if (VARIANT == 0)
+    {
+        slam_axis_prepare(&PX, sx);
+        slam_axis_prepare(&PY, sy);
+        slam_cell_of(a.rows, sx, sy, &i0, &j0);
+    }
+    const bool origin_in = slam_in_bounds(a.rows, a.cols, i0, j0);
+    const unsigned off0 = (unsigned)(slam_mul24(i0, a.cols + 4) + j0 + 2 * (a.cols + 4) + 2);
     for (int b0 = 0; b0 < a.B; b0 += 64)
     {
         const int b = b0 + lane;
@@ -176,12 +187,16 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
             dm_sincos(theta, &s, &c);
             slam_ray_result r;
             if (VARIANT == 0)
-                ray_fast_L(a.grid, (unsigned)a.map_stride, a.cols + 4, a.rows, a.cols, sx, sy, c, s, a.zmax2, a.k_safe, &r, nullptr,
-                           a.clamp_limit ? slam_sample_limit(a.z[b], a.stddev) : SLAM_NO_SAMPLE_LIMIT);
+            {
+                const unsigned plane_off = (unsigned)slam_octant(c, s) * (unsigned)a.map_stride;
+                const unsigned e0 = origin_in ? a.grid[off0 + plane_off] : 0u;
+                ray_fast_L0(a.grid, plane_off, a.cols + 4, a.rows, a.cols, &PX, &PY, c, s, a.zmax2, a.k_safe,
+                            a.clamp_limit ? slam_sample_limit(a.z[b], a.stddev) : SLAM_NO_SAMPLE_LIMIT, i0, j0, e0, &r, nullptr);
+            }
             else
                 ray_walk<false, true>(a.grid, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, nullptr, nullptr,
                                       a.max_iter, &r, &st);
-            lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps);
+            lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps, VARIANT == 0 ? a.inv_stddev : 0.0);
             if (a.hit_xy)
             {
                 const size_t o = (size_t)p * a.B + b;
