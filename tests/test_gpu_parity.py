@@ -337,6 +337,37 @@ def test_cone_planes_built_on_the_device_equal_the_host_construction(sa):
             assert np.array_equal(a, b), f"plane {o} of a {rows}x{cols} map: {np.argwhere(a != b)[:5]}"
 
 
+def test_kernel_shape_and_order_follow_the_cloud_without_changing_a_bit(sa):
+    """do_weights chooses per pass from the cloud's extent (k_order_keys / k_order_box leave it on the device and in
+    pinned host memory): lanes over particles for a dense cloud, the wave-per-particle kernel for a sparse one (more
+    than 4 cells of bounding box per particle), heading-first or place-first order.  A uniformly seeded cloud on the
+    maze starts under the first and is switched to the second a pass later; a Gaussian cloud seeded afterwards goes
+    back.  Every pass of one cloud must give the same bits, and a subset must equal the oracle."""
+    free = orc.load_map("maze")
+    g = (free * 255).astype(np.uint8)
+    rows, cols = g.shape
+    N, B = 20000, 90
+    ang, dist = orc.make_scan(free, [1944.5, 2188.5, 1.2], OFFSET, B)
+    f = sa.Filter(N, rows, cols, seed=99, sort=sa.capi.SORT_NONE)
+    f.set_map(g)
+    for seeding in ("uniform", "gaussian", "uniform"):
+        if seeding == "uniform":
+            f.seed_uniform_free()  # 290 cells of bounding box per particle: sparse
+        else:
+            f.seed_gaussian([1944.5, 2188.5, 1.2], [3.0, 3.0, 0.1])  # far below one cell per particle: dense
+        x, y, th = f.poses()
+        ws = []
+        for _ in range(4):
+            f.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+            ws.append(f.weights())
+        for k in range(1, 4):
+            assert_bits(ws[k], ws[0], f"{seeding} cloud: pass {k} against pass 0")
+        sub = np.arange(0, N, 997)
+        ow, _ = orc.update_weights(x[sub], y[sub], th[sub], g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET)
+        assert_bits(ws[0][sub], ow, f"{seeding} cloud: subset vs oracle")
+    f.close()
+
+
 def test_one_chebyshev_plane_in_place_of_the_cone_planes(sa, tmp_path):
     """Maps too large for eight planes below 4 GiB get ONE plane of Chebyshev clearance (plane stride 0).  The choice is
     made when the map is set; SLAM_CONE_PLANES=0 forces it in a child process, whose weights and hits must equal the ones
