@@ -156,8 +156,10 @@ template <int VARIANT>
 __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= a.n) return;  // whole wavefront
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= a.n) return;  // whole wavefront
+    // (a.order: the particles in place order, so that the wavefronts in flight work on one band of a large map)
+    const int64_t p = a.order ? (int64_t)a.order[slot] : slot;
     const double px = a.x[p], py = a.y[p], pth = a.th[p];
     double s0, c0;
     dm_sincos(pth + a.stheta, &s0, &c0);

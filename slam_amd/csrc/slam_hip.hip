@@ -700,8 +700,25 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     {
         a.grid = h->clr;
         a.map_stride = h->clr_stride;
-        if (sparse_cloud)
-        {  // (k_order_keys does not run on this path: the box of this pass from a launch of its own)
+        if (sparse_cloud && h->okeys && tuning().order_bits == 32 && tuning().order_wide)
+        {
+            // the particles in place order (the same keys and sort as for lanes over particles; k_order_keys also leaves
+            // this pass's bounding box): wavefronts that run together then read one band of the planes
+            hipLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th,
+                               tuning().order_wide, 32, h->okeys, h->oident, h->stats, (const double*)nullptr, h->scan_dev, 0, h->obox,
+                               h->order_pass++ & 1, tuning().order_wide, h->obox_host);
+            h->poses_reset = false;
+            if (use_sample_sort(h, 2))
+                sortk::sort_pairs(h->ss_tmp, h->okeys, h->oident, h->order, h->n, tuning().order_coarse != 0, h->stream);
+            else
+            {
+                size_t bytes = h->osort_tmp_bytes;
+                HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, 32, h->stream));
+            }
+            a.order = h->order;
+        }
+        else if (sparse_cloud)
+        {  // (no order: the box of this pass from a launch of its own)
             hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, h->order_pass++ & 1, h->obox_host);
             h->poses_reset = false;
         }
