@@ -244,6 +244,7 @@ struct Tuning
     int clamp_limit; // SLAM_RAY_CLAMP_LIMIT: 1 = the localization hit search stops beyond z + 4 sigma (default), 0 = always to max_dist
     int cone_build;  // SLAM_CONE_BUILD: 1 = the cone-clearance planes are built on the device (default), 0 = on the host
     int order_wide;  // SLAM_PL_ORDER_WIDE: order mode for a cloud spread over more than 2^22 cells (0 = never switch)
+    int order_sparse;// SLAM_PL_ORDER_SPARSE: order mode of the wave-per-particle kernel on a sparse cloud (0 = index order)
     int beam_cells;  // SLAM_BEAM_CELLS: cells of the cloud's bounding box per particle above which the wave-per-particle kernel runs (0 = never)
     int tile_fuse;   // SLAM_TILE_FUSE: 1 = the two-phase kernel makes the planned tile copies itself (default), 0 = k_tile_copy before it
 };
@@ -255,7 +256,7 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 2 | (5 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 2 | (5 << 4) | (6 << 8)), env_int("SLAM_PL_ORDER_SPARSE", 4 | (7 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1)};
     return t;
 }
 
@@ -263,16 +264,45 @@ const Tuning& tuning()
 bool use_sample_sort(const slam_mcl* h, int which) { return h->ss_tmp && (tuning().sort_impl & which) && h->n >= sortk::MIN_N && h->n <= sortk::MAX_N; }
 
 // The cloud's bounding boxes (k_order_keys / k_order_box): two on the device, the latest one also in pinned host memory.
+// ... and the buffers of the pose-coherent order (keys, identity, order, rocPRIM scratch).
 int ensure_order_box(slam_mcl* h)
 {
-    if (h->obox) return SLAM_OK;
+    if (h->obox && h->okeys) return SLAM_OK;
     int rc;
+    if (!h->okeys)
+    {
+        if ((rc = dev_alloc(&h->okeys, h->n)) || (rc = dev_alloc(&h->okeys2, h->n)) || (rc = dev_alloc(&h->oident, h->n)) ||
+            (rc = dev_alloc(&h->order, h->n)))
+            return rc;
+        size_t bytes = 0;
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, 32, h->stream));
+        uint8_t* tmp = nullptr;
+        if ((rc = dev_alloc(&tmp, bytes ? bytes : 16))) return rc;
+        h->osort_tmp = tmp;
+        h->osort_tmp_bytes = bytes;
+    }
+    if (h->obox) return SLAM_OK;
     if ((rc = dev_alloc(&h->obox, 8))) return rc;
     // both boxes empty (max < min): the first pass keeps the default order and the default kernel shape
     const int empty[8] = {0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1, 0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1};
     HIPCHK(hipMemcpy(h->obox, empty, sizeof(empty), hipMemcpyHostToDevice));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->obox_host), 4 * sizeof(int), hipHostMallocDefault));
     for (int k = 0; k < 4; ++k) h->obox_host[k] = empty[k];
+    return SLAM_OK;
+}
+
+// After the poses were set or seeded (set-up calls, which may wait): the cloud's box on the device and on the host, so that
+// the very first weighting pass already gets the order and the kernel shape of the cloud it meets.
+int refresh_cloud_box(slam_mcl* h)
+{
+    if (h->prm.mode != SLAM_MODE_LOCALIZATION || h->prm.raycaster != SLAM_RAYCAST_FAST || h->n < 4096 || tuning().order_mode <= 0)
+        return SLAM_OK;
+    int rc = ensure_order_box(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, (h->order_pass + 1) & 1, h->obox_host);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->poses_reset = false;
     return SLAM_OK;
 }
 
@@ -615,20 +645,9 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         bool ext_started = false;
         if (order_mode > 0)
         {
-            if (!h->okeys)
             {
-                int rc;
-                if ((rc = ensure_order_box(h))) return rc;
-                if ((rc = dev_alloc(&h->okeys, h->n)) || (rc = dev_alloc(&h->okeys2, h->n)) ||
-                    (rc = dev_alloc(&h->oident, h->n)) || (rc = dev_alloc(&h->order, h->n)))
-                    return rc;
-                size_t bytes = 0;
-                HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0,
-                                                 32, h->stream));
-                uint8_t* tmp = nullptr;
-                if ((rc = dev_alloc(&tmp, bytes ? bytes : 16))) return rc;
-                h->osort_tmp = tmp;
-                h->osort_tmp_bytes = bytes;
+                int rc = ensure_order_box(h);
+                if (rc) return rc;
             }
             if (h->poses_reset)
             {  // poses set or seeded since the last pass: the box this pass reads comes from the new cloud
@@ -700,13 +719,14 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     {
         a.grid = h->clr;
         a.map_stride = h->clr_stride;
-        if (sparse_cloud && h->okeys && tuning().order_bits == 32 && tuning().order_wide)
+        if (sparse_cloud && h->okeys && tuning().order_bits == 32 && tuning().order_sparse)
         {
-            // the particles in place order (the same keys and sort as for lanes over particles; k_order_keys also leaves
-            // this pass's bounding box): wavefronts that run together then read one band of the planes
+            // the particles in place order (keys and sort as for lanes over particles, but Morton order of 64-cell tiles:
+            // with one particle per wavefront a square neighbourhood beats a band, 340 -> 299 ms on the 16384^2 shard;
+            // k_order_keys also leaves this pass's bounding box): wavefronts that run together read one part of the planes
             hipLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th,
-                               tuning().order_wide, 32, h->okeys, h->oident, h->stats, (const double*)nullptr, h->scan_dev, 0, h->obox,
-                               h->order_pass++ & 1, tuning().order_wide, h->obox_host);
+                               tuning().order_sparse, 32, h->okeys, h->oident, h->stats, (const double*)nullptr, h->scan_dev, 0, h->obox,
+                               h->order_pass++ & 1, tuning().order_sparse, h->obox_host);
             h->poses_reset = false;
             if (use_sample_sort(h, 2))
                 sortk::sort_pairs(h->ss_tmp, h->okeys, h->oident, h->order, h->n, tuning().order_coarse != 0, h->stream);
@@ -1202,7 +1222,7 @@ SLAM_API int slam_mcl_set_poses(slam_mcl* h, const double* x, const double* y, c
     HIPCHK(hipMemcpy(h->x + first, x, sizeof(double) * count, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->y + first, y, sizeof(double) * count, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->th + first, theta, sizeof(double) * count, hipMemcpyHostToDevice));
-    return SLAM_OK;
+    return refresh_cloud_box(h);
 }
 
 SLAM_API int slam_mcl_set_weights(slam_mcl* h, const double* w, int64_t first, int64_t count)
@@ -1231,6 +1251,7 @@ SLAM_API int slam_mcl_seed_gaussian(slam_mcl* h, const double mean[3], const dou
     hipLaunchKernelGGL(slamk::k_seed_gaussian, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->y,
                        h->th, h->w, mean[0], mean[1], mean[2], sigma[0], sigma[1], sigma[2], h->prm.seed,
                        (uint64_t)h->prm.global_first, 1.0 / (double)h->prm.global_n);
+    if ((rc = refresh_cloud_box(h))) return rc;
     return finish(h);
 }
 
@@ -1244,6 +1265,7 @@ SLAM_API int slam_mcl_seed_uniform_free(slam_mcl* h)
     hipLaunchKernelGGL(slamk::k_seed_uniform_free, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->y,
                        h->th, h->w, h->grid, h->rows, h->cols, h->prm.seed, (uint64_t)h->prm.global_first,
                        1.0 / (double)h->prm.global_n);
+    if ((rc = refresh_cloud_box(h))) return rc;
     return finish(h);
 }
 

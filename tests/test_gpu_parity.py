@@ -340,9 +340,10 @@ def test_cone_planes_built_on_the_device_equal_the_host_construction(sa):
 def test_kernel_shape_and_order_follow_the_cloud_without_changing_a_bit(sa):
     """do_weights chooses per pass from the cloud's extent (k_order_keys / k_order_box leave it on the device and in
     pinned host memory): lanes over particles for a dense cloud, the wave-per-particle kernel for a sparse one (more
-    than 4 cells of bounding box per particle), heading-first or place-first order.  A uniformly seeded cloud on the
-    maze starts under the first and is switched to the second a pass later; a Gaussian cloud seeded afterwards goes
-    back.  Every pass of one cloud must give the same bits, and a subset must equal the oracle."""
+    than 4 cells of bounding box per particle), heading-first or place-first order.  The seeding calls refresh the
+    extent, so a uniformly seeded cloud on the maze gets the second kernel from its first pass on and a Gaussian cloud
+    seeded afterwards the first again.  Every pass of one cloud must give the same bits, and a subset must equal the
+    oracle (which is how the two kernels are compared with each other)."""
     free = orc.load_map("maze")
     g = (free * 255).astype(np.uint8)
     rows, cols = g.shape
@@ -1371,8 +1372,8 @@ def test_full_shard_sizes_of_configs_3_and_5(sa, size, N, B, zmax, uniform):
     osub = sub[:24]
     olw, _ = orc.update_weights(x[osub], y[osub], th[osub], g, ang, dist, 0.5, zmax, OFFSET, math=orc.DET, log_domain=True)
     assert_bits(lw[osub], olw, "subset vs oracle")
-    # the second pass knows the cloud's extent (k_order_keys): the uniform cloud over 16384^2 is then dealt to the
-    # wavefronts by place first, the Gaussian one stays with the heading first: same bits either way
+    # (both passes know the cloud's extent: the uniform cloud over 16384^2 runs on the wave-per-particle kernel in place
+    # order, the Gaussian one on lanes over particles with the heading first)
     f.synchronize()
     t0 = time.perf_counter()
     f.update_weights(ang, dist, 0.5, zmax, OFFSET)
