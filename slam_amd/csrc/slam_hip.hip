@@ -256,7 +256,7 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 2 | (5 << 4) | (6 << 8)), env_int("SLAM_PL_ORDER_SPARSE", 4 | (7 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 4 | (7 << 4) | (8 << 8)), env_int("SLAM_PL_ORDER_SPARSE", 4 | (7 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1)};
     return t;
 }
 
