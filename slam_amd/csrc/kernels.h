@@ -155,6 +155,12 @@ struct WeightArgs
 template <int VARIANT>
 __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
 {
+    // the beams' log-likelihoods wait here for lane 0 to add them in beam order at the end (one dependent add per beam;
+    // adding them group by group took two readlanes per add as well); scans longer than the slab keep the readlane form
+    enum { LW_CAP = 1280 };
+    __shared__ double lw_s[4][LW_CAP];
+    double* lw_mine = lw_s[threadIdx.x >> 6];
+    const bool lw_in_lds = a.B <= LW_CAP;
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= a.n) return;  // whole wavefront
@@ -207,8 +213,22 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
                 a.hit_cell[o] = r.hcell;
             }
         }
-        const int cnt = (a.B - b0) < 64 ? (a.B - b0) : 64;
-        for (int l = 0; l < cnt; ++l) acc += readlane_f64(lw, l);
+        if (lw_in_lds)
+        {
+            if (b < a.B) lw_mine[b] = lw;
+        }
+        else
+        {
+            const int cnt = (a.B - b0) < 64 ? (a.B - b0) : 64;
+            for (int l = 0; l < cnt; ++l) acc += readlane_f64(lw, l);
+        }
+    }
+    if (lw_in_lds)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0)
+            for (int b = 0; b < a.B; ++b) acc += lw_mine[b];  // slam/mcl.cpp:69-74
     }
     if (lane == 0) a.w[p] = a.log_domain ? acc : dm_exp(acc);
     if (VARIANT == 1 && a.stats)
