@@ -211,6 +211,24 @@ int slam_mcl_shard_resample(slam_mcl* h, const double* gathered_state_dev, int32
 int slam_mcl_shard_resample_split(slam_mcl* h, const double* gathered_poses_dev, const double* gathered_weights_dev,
                                   int32_t n_shards);
 
+/* What the caller reads after every step, across shards: slam::average_pose over ALL particles
+ * (slam/util.cpp:66-85, called at apps/grid_slam.cpp:119) and get_particles().front(), the heaviest particle
+ * (apps/grid_slam.cpp:112; front of the order slam/mcl.cpp:236-238 establishes: weight descending, and the lowest
+ * global slot among equals, which is what SLAM_SORT_FULL puts first on one handle).  Sharded handles do not sort
+ * (SLAM_SORT_NONE), so: every shard reduces its own particles with slam_mcl_shard_summary
+ *   out = { sum x, sum y, sum cos(theta), sum sin(theta), n_particles, best weight, its global slot, its local slot },
+ * the driver all-gathers the SLAM_SHARD_SUMMARY_DOUBLES doubles of every shard in rank order (64 B per rank, one
+ * collective), and slam_shard_summary_combine (host arithmetic only, the same on every rank) adds the sums in rank
+ * order, divides (slam/util.cpp:80-82) and picks the winner.  The shard that owns the winner serves its pose and
+ * canvas (slam_mcl_get_poses / slam_mcl_get_map_u8 at best_local_slot).  The sums are floating point: the mean pose
+ * agrees with the unsharded slam_mcl_average_pose to rounding (different summation order; tests: 1e-12 relative),
+ * the winner is exact.  Any output pointer of the combine call may be NULL. */
+#define SLAM_SHARD_SUMMARY_DOUBLES 8
+int slam_mcl_shard_summary(slam_mcl* h, double out[SLAM_SHARD_SUMMARY_DOUBLES]);
+int slam_shard_summary_combine(const double* summaries /* [n_shards][SLAM_SHARD_SUMMARY_DOUBLES] */, int32_t n_shards,
+                               double avg_pose[3], double* best_weight, int64_t* best_global_slot, int32_t* best_shard,
+                               int64_t* best_local_slot);
+
 /* Sharded resampling in SLAM mode (per-particle canvases, slam/mcl.cpp:147-155,205-227): the
  * selected particles' canvases live on the shard that owns the source, so the step has an exchange
  * of whole canvases between the two halves:
@@ -249,6 +267,10 @@ int slam_mcl_pack_tiles(slam_mcl* h, const int32_t* local_idx_dev, int64_t count
                         uint8_t* tiles_out_dev, int64_t n_tiles);
 int slam_mcl_shard_import_tiles(slam_mcl* h, const int32_t* tabs_dev, int64_t n_tabs, const uint8_t* tiles_dev,
                                 int64_t n_tiles, const int32_t* pos_dev);
+/* The shift of step 3' on the device, for drivers without a tensor library (slam::ShardedMCL): every entry > 0 of the
+ * n_tabs tables at tabs_dev (one owner's answer) grows by first_tile, the position of that owner's first tile in the
+ * concatenated payload.  Enqueued on the handle's stream. */
+int slam_mcl_shift_tables(slam_mcl* h, int32_t* tabs_dev, int64_t n_tabs, int32_t first_tile);
 typedef struct slam_mcl_device_maps
 {
     uint8_t* maps_dev;       /* n_particles canvases, map_stride bytes apart (rows*cols valid bytes each); NULL if tiled */

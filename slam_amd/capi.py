@@ -15,6 +15,7 @@ RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC = 0, 1
 SORT_FULL, SORT_NONE = 0, 1
 WEIGHT_LINEAR, WEIGHT_LOG = 0, 1
 TILE_SIDE, TILE_BYTES = 64, 4096  # SLAM_TILE_SIDE, SLAM_TILE_BYTES of include/slam_hip.h
+SHARD_SUMMARY_DOUBLES = 8         # SLAM_SHARD_SUMMARY_DOUBLES
 MAPS_AUTO, MAPS_DENSE, MAPS_TILED = 0, 1, 2
 RAYCAST_FAST, RAYCAST_WALK, RAYCAST_FAST_BEAM_LANES, RAYCAST_FAST_PARTICLE_LANES, RAYCAST_TWO_PHASE, RAYCAST_TWO_PHASE_LITERAL = 0, 1, 2, 3, 4, 5
 RAYCAST_FAST_PARTICLE_LANES_DIRECT = 6
@@ -97,6 +98,7 @@ SYMBOLS = {
     "slam_mcl_pack_tiles_count": (ctypes.c_int, [_P, _P, _I64, _P]),
     "slam_mcl_pack_tiles": (ctypes.c_int, [_P, _P, _I64, _P, _P, _I64]),
     "slam_mcl_shard_import_tiles": (ctypes.c_int, [_P, _P, _I64, _P, _I64, _P]),
+    "slam_mcl_shift_tables": (ctypes.c_int, [_P, _P, _I64, _I32]),
     "slam_mcl_device_maps_get": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_tile_stats": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_poses": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64]),
@@ -109,6 +111,8 @@ SYMBOLS = {
     "slam_mcl_record_hits": (ctypes.c_int, [_P, _I32]),
     "slam_mcl_collect_stats": (ctypes.c_int, [_P, _I32]),
     "slam_mcl_average_pose": (ctypes.c_int, [_P, _P]),
+    "slam_mcl_shard_summary": (ctypes.c_int, [_P, _P]),
+    "slam_shard_summary_combine": (ctypes.c_int, [_P, _I32, _P, _P, _P, _P, _P]),
     "slam_mcl_get_stats": (ctypes.c_int, [_P, _P]),
     "slam_mcl_profile": (ctypes.c_int, [_P, _I32]),
     "slam_mcl_get_kernel_ms": (ctypes.c_int, [_P, _P, _P, _I32]),

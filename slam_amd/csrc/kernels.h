@@ -1448,6 +1448,16 @@ __global__ void __launch_bounds__(256) k_tiles_copy(const uint8_t* from, const i
     t[threadIdx.x] = f[threadIdx.x];
 }
 
+// received tables of one owner: entries count from 1 within that owner's payload; shift them by the position of the
+// owner's first tile in the receiver's concatenated payload (0 = the blank tile stays 0)
+__global__ void __launch_bounds__(256) k_shift_tabs(int32_t* tabs, int64_t total, int32_t add)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const int32_t e = tabs[k];
+    if (e > 0) tabs[k] = e + add;
+}
+
 // slot p takes row pos[p] of the received tables; entry e > 0 = payload tile e - 1, now pool tile ids[e - 1]
 __global__ void __launch_bounds__(256) k_import_tabs(const int32_t* tabs, const int32_t* pos, int T, int64_t total, int n_tiles,
                                                      const int32_t* ids, int32_t* tab, int64_t n_tabs, int* bad)
@@ -1635,6 +1645,38 @@ __global__ void __launch_bounds__(256) k_pose_partials(int64_t n, const double* 
     }
     if (threadIdx.x == 0)
         for (int q = 0; q < 4; ++q) partial[4 * blockIdx.x + q] = sh[q][0];
+}
+
+// The heaviest particle of a shard: per block the largest weight and the lowest slot that holds it — the front of the
+// order (weight descending, slot ascending) that slam/mcl.cpp:236-238 establishes and apps/grid_slam.cpp:112 reads.
+// best[2 * block] = weight, best[2 * block + 1] = slot (as a double: exact below 2^53).  NaN weights never win.
+__global__ void __launch_bounds__(256) k_best_partials(int64_t n, const double* w, double* best /* 2 per block */)
+{
+    __shared__ double sw[256];
+    __shared__ int64_t si[256];
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    sw[threadIdx.x] = p < n ? w[p] : -__builtin_huge_val();
+    si[threadIdx.x] = p < n ? p : INT64_MAX;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1)
+    {
+        if ((int)threadIdx.x < d)
+        {
+            const double a = sw[threadIdx.x], b = sw[threadIdx.x + d];
+            const int64_t ia = si[threadIdx.x], ib = si[threadIdx.x + d];
+            if (b > a || (b == a && ib < ia) || (a != a && b == b))
+            {
+                sw[threadIdx.x] = b;
+                si[threadIdx.x] = ib;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        best[2 * blockIdx.x] = sw[0];
+        best[2 * blockIdx.x + 1] = (double)si[0];
+    }
 }
 
 // Batched read-only raycasts (slam/raycast.cpp:53-141), one thread per ray.

@@ -1012,7 +1012,7 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
     TRY(dev_alloc(&h->keys2, n));
     TRY(dev_alloc(&h->stats, 3));
     TRY(dev_alloc(&h->luts, 512));
-    TRY(dev_alloc(&h->partials, 4 * (size_t)cdiv(n, 256)));
+    TRY(dev_alloc(&h->partials, 6 * (size_t)cdiv(n, 256)));  // average_pose: 4 per block; shard_summary: + 2
     if (h->prm.weight_domain != SLAM_WEIGHT_LINEAR && h->prm.weight_domain != SLAM_WEIGHT_LOG)
         rc = fail(SLAM_ERR_ARG, "weight_domain must be SLAM_WEIGHT_LINEAR or SLAM_WEIGHT_LOG");
     if (h->prm.weight_domain == SLAM_WEIGHT_LOG)
@@ -1573,6 +1573,21 @@ SLAM_API int slam_mcl_pack_tiles(slam_mcl* h, const int32_t* local_idx_dev, int6
     return maybe_finish(h);
 }
 
+SLAM_API int slam_mcl_shift_tables(slam_mcl* h, int32_t* tabs_dev, int64_t n_tabs, int32_t first_tile)
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (h->prm.mode != SLAM_MODE_SLAM || !h->tiled) return fail(SLAM_ERR_STATE, "shift_tables: SLAM mode with tiled canvases only");
+    if (n_tabs < 0 || (n_tabs > 0 && !tabs_dev) || first_tile < 0) return fail(SLAM_ERR_ARG, "shift_tables: bad argument");
+    const int64_t total = n_tabs * h->tile_T;
+    if (total > 0 && first_tile > 0)
+    {
+        hipLaunchKernelGGL(slamk::k_shift_tabs, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, h->stream, tabs_dev, total, first_tile);
+        HIPCHK(hipGetLastError());
+    }
+    return SLAM_OK;
+}
+
 SLAM_API int slam_mcl_shard_import_tiles(slam_mcl* h, const int32_t* tabs_dev, int64_t n_tabs, const uint8_t* tiles_dev,
                                          int64_t n_tiles, const int32_t* pos_dev)
 {
@@ -1752,6 +1767,68 @@ SLAM_API int slam_mcl_average_pose(slam_mcl* h, double out[3])
     out[0] = s[0] / (double)h->n;  // slam/util.cpp:80-82
     out[1] = s[1] / (double)h->n;
     out[2] = std::atan2(s[3], s[2]);
+    return SLAM_OK;
+}
+
+SLAM_API int slam_mcl_shard_summary(slam_mcl* h, double out[SLAM_SHARD_SUMMARY_DOUBLES])
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out) return fail(SLAM_ERR_ARG, "null");
+    const int64_t nb = cdiv(h->n, 256);
+    hipLaunchKernelGGL(slamk::k_pose_partials, dim3((unsigned)nb), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th,
+                       h->partials);
+    hipLaunchKernelGGL(slamk::k_best_partials, dim3((unsigned)nb), dim3(256), 0, h->stream, h->n, h->w, h->partials + 4 * (size_t)nb);
+    HIPCHK(hipGetLastError());
+    std::vector<double> part(6 * (size_t)nb);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(part.data(), h->partials, sizeof(double) * part.size(), hipMemcpyDeviceToHost));
+    double s[4] = {0, 0, 0, 0};
+    for (int64_t b = 0; b < nb; ++b)
+        for (int q = 0; q < 4; ++q) s[q] += part[4 * (size_t)b + q];
+    const double* best = part.data() + 4 * (size_t)nb;
+    double bw = best[0], bi = best[1];
+    for (int64_t b = 1; b < nb; ++b)  // blocks in slot order: a later block wins only with a larger weight
+        if (best[2 * b] > bw || (bw != bw && best[2 * b] == best[2 * b]))
+        {
+            bw = best[2 * b];
+            bi = best[2 * b + 1];
+        }
+    for (int q = 0; q < 4; ++q) out[q] = s[q];
+    out[4] = (double)h->n;
+    out[5] = bw;
+    out[6] = (double)h->prm.global_first + bi;
+    out[7] = bi;
+    return SLAM_OK;
+}
+
+SLAM_API int slam_shard_summary_combine(const double* summaries, int32_t n_shards, double avg_pose[3], double* best_weight,
+                                        int64_t* best_global_slot, int32_t* best_shard, int64_t* best_local_slot)
+{
+    if (!summaries || n_shards < 1) return fail(SLAM_ERR_ARG, "shard_summary_combine: no summaries");
+    double s[4] = {0, 0, 0, 0}, count = 0;
+    int win = 0;
+    for (int r = 0; r < n_shards; ++r)
+    {
+        const double* q = summaries + (size_t)r * SLAM_SHARD_SUMMARY_DOUBLES;
+        for (int k = 0; k < 4; ++k) s[k] += q[k];  // shards in rank order: the same bits on every rank
+        count += q[4];
+        const double* b = summaries + (size_t)win * SLAM_SHARD_SUMMARY_DOUBLES;
+        // (weight descending, global slot ascending): the front of slam/mcl.cpp:236-238's order
+        if (q[5] > b[5] || (q[5] == b[5] && q[6] < b[6]) || (b[5] != b[5] && q[5] == q[5])) win = r;
+    }
+    if (!(count >= 1)) return fail(SLAM_ERR_ARG, "shard_summary_combine: no particles");
+    const double* b = summaries + (size_t)win * SLAM_SHARD_SUMMARY_DOUBLES;
+    if (avg_pose)
+    {
+        avg_pose[0] = s[0] / count;  // slam/util.cpp:80-82
+        avg_pose[1] = s[1] / count;
+        avg_pose[2] = std::atan2(s[3], s[2]);
+    }
+    if (best_weight) *best_weight = b[5];
+    if (best_global_slot) *best_global_slot = (int64_t)b[6];
+    if (best_shard) *best_shard = win;
+    if (best_local_slot) *best_local_slot = (int64_t)b[7];
     return SLAM_OK;
 }
 

@@ -42,6 +42,9 @@ class HipShard:
     def set_map(self, grid):
         self.f.set_map(grid)
 
+    def canvas_shape(self):
+        return (self.f.rows, self.f.cols)
+
     def predict(self, odom, alphas):
         self.f.predict(odom, alphas)
 
@@ -59,6 +62,17 @@ class HipShard:
 
     def shard_resample_split(self, gathered_poses, gathered_weights, world):
         self.f.shard_resample_split(gathered_poses.data_ptr(), gathered_weights.data_ptr(), world)
+
+    # what the caller reads every frame (apps/grid_slam.cpp:112-119), this shard's part
+    def summary(self):
+        return torch.from_numpy(self.f.shard_summary())
+
+    def pose_of(self, local_slot):
+        x, y, th = self.f.poses(int(local_slot), 1)
+        return float(x[0]), float(y[0]), float(th[0])
+
+    def map_of(self, local_slot):
+        return torch.from_numpy(self.f.map_of(int(local_slot)))
 
     # SLAM mode: the three local pieces around the canvas exchange
     def shard_select(self, gathered, world):
@@ -130,6 +144,63 @@ class ShardedFilter:
         with torch.cuda.stream(self._comm):
             dist.all_gather_into_tensor(self._gp, local[:n3], group=self.group)
             self._poses_done = self._comm.record_event()
+
+    # ---- read-out across ranks: slam::average_pose and get_particles().front() ------------------------------------
+    def summarize(self):
+        """One small all-gather (64 B per rank): every rank's {sum x, sum y, sum cos, sum sin, n, best weight, best
+        global slot, best local slot}, combined in rank order by the library's host arithmetic, so every rank holds the
+        same bits.  Returns (Pose-like (x, y, theta) mean of ALL particles: slam/util.cpp:66-85 at apps/grid_slam.cpp:119;
+        best = dict(weight, global_slot, rank, local_slot): the particle a sorted unsharded filter holds at the front,
+        slam/mcl.cpp:236-238 with ties to the lowest slot)."""
+        import ctypes
+
+        import numpy as np
+
+        mine = self.b.summary().to(torch.float64).reshape(-1)
+        if self.world > 1 or self.always_collective:
+            dev = self._gathered.device
+            allq = torch.empty(self.world * mine.numel(), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allq, mine.to(dev), group=self.group)
+            allq = allq.cpu()
+        else:
+            allq = mine
+        q = np.ascontiguousarray(allq.numpy(), dtype=np.float64)
+        lib = capi.load_library()
+        avg = np.empty(3)
+        bw, slot, rank, loc = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int64()
+        capi.check(lib.slam_shard_summary_combine(capi.ptr(q), self.world, capi.ptr(avg), ctypes.byref(bw), ctypes.byref(slot),
+                                                  ctypes.byref(rank), ctypes.byref(loc)), lib)
+        return (float(avg[0]), float(avg[1]), float(avg[2])), {"weight": bw.value, "global_slot": slot.value, "rank": rank.value,
+                                                               "local_slot": loc.value}
+
+    def average_pose(self):
+        return self.summarize()[0]
+
+    def best(self, with_map=False):
+        """get_particles().front() of the whole filter: pose, weight and (SLAM mode, with_map) canvas of the heaviest
+        particle, served by the rank that owns it (one broadcast of 24 B, plus rows x cols bytes for the canvas)."""
+        _, best = self.summarize()
+        me = dist.get_rank(self.group) if (dist.is_initialized() and self.world > 1) else 0
+        dev = self._gathered.device
+        pose = torch.zeros(3, dtype=torch.float64)
+        if me == best["rank"]:
+            pose = torch.tensor(self.b.pose_of(best["local_slot"]), dtype=torch.float64)
+        canvas = None
+        if self.world > 1:
+            src = dist.get_global_rank(self.group, best["rank"]) if self.group is not None else best["rank"]
+            pose = pose.to(dev)
+            dist.broadcast(pose, src=src, group=self.group)
+            pose = pose.cpu()
+        if with_map and getattr(self.b, "slam_mode", False):
+            if me == best["rank"]:
+                canvas = self.b.map_of(best["local_slot"]).to(dev)
+            if self.world > 1:
+                if canvas is None:
+                    canvas = torch.empty(self.b.canvas_shape(), dtype=torch.uint8, device=dev)
+                dist.broadcast(canvas, src=src, group=self.group)
+            canvas = canvas.cpu().numpy()
+        best.update(x=float(pose[0]), y=float(pose[1]), theta=float(pose[2]), map=canvas)
+        return best
 
     def update(self, angles, dists, stddev, max_dist, offset=(0.0, 0.0, 0.0)):
         self.b.update_weights(angles, dists, stddev, max_dist, offset)

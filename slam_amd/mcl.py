@@ -265,6 +265,13 @@ class Filter:
         check(self.lib.slam_mcl_average_pose(self._h, ptr(out)), self.lib)
         return Pose(*out)
 
+    def shard_summary(self):
+        """This shard's part of average_pose and its heaviest particle (slam_mcl_shard_summary): 8 doubles
+        {sum x, sum y, sum cos, sum sin, n, best weight, best global slot, best local slot}."""
+        out = np.empty(capi.SHARD_SUMMARY_DOUBLES)
+        check(self.lib.slam_mcl_shard_summary(self._h, ptr(out)), self.lib)
+        return out
+
     def stats(self):
         out = np.zeros(3, dtype=np.int64)
         check(self.lib.slam_mcl_get_stats(self._h, ptr(out)), self.lib)

@@ -48,6 +48,22 @@ class OracleShard:
     def new_gather_buffer(self, world):
         return torch.empty(world * 4 * self.n, dtype=torch.float64)
 
+    # read-out across ranks (HipShard.summary / pose_of / map_of): slam/util.cpp:66-85 and the front of slam/mcl.cpp:236-238
+    def summary(self):
+        c, s = orc.detmath(1, self.th), orc.detmath(0, self.th)
+        k = int(np.flatnonzero(self.w == self.w.max())[0])
+        return torch.tensor([self.x.sum(), self.y.sum(), c.sum(), s.sum(), float(self.n), self.w[k], float(self.first + k), float(k)],
+                            dtype=torch.float64)
+
+    def pose_of(self, k):
+        return float(self.x[k]), float(self.y[k]), float(self.th[k])
+
+    def map_of(self, k):
+        return torch.from_numpy(self.maps[k].copy())
+
+    def canvas_shape(self):
+        return self.maps.shape[1:]
+
     # SLAM mode (per-particle canvases): same three pieces as HipShard
     slam_mode = False
 
@@ -141,8 +157,11 @@ def main_slam(out, n_total, steps):
     for _ in range(steps):
         sf.predict([0.0, 0.5, 0.0], ALPHAS)
         sf.update(ang, dscan, 2.0, SLAM_ZMAX, SLAM_OFFSET)
+    avg, _ = sf.summarize()
+    best = sf.best(with_map=True)
     np.savez(os.path.join(out, f"rank{rank}.npz"), x=shard.x, y=shard.y, th=shard.th, w=shard.w, idx=shard.last_idx,
-             maps=shard.maps)
+             maps=shard.maps, avg=np.array(avg)[None], best=np.array([[best["weight"], best["global_slot"], best["rank"], best["x"],
+                                                                      best["y"], best["theta"]]]), best_map=best["map"][None])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -165,7 +184,11 @@ def main():
     for _ in range(steps):
         sf.predict(ODOM, ALPHAS)
         sf.update(ang, dscan, 5.0, 500.0, OFFSET)
-    np.savez(os.path.join(out, f"rank{rank}.npz"), x=shard.x, y=shard.y, th=shard.th, w=shard.w, idx=shard.last_idx)
+    avg, _ = sf.summarize()
+    best = sf.best()
+    np.savez(os.path.join(out, f"rank{rank}.npz"), x=shard.x, y=shard.y, th=shard.th, w=shard.w, idx=shard.last_idx,
+             avg=np.array(avg)[None], best=np.array([[best["weight"], best["global_slot"], best["rank"], best["x"], best["y"],
+                                                      best["theta"]]]))
     dist.barrier()
     dist.destroy_process_group()
 

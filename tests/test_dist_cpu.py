@@ -23,8 +23,27 @@ def run_world(tmp_path, world, n_total, steps, mode="loc", wire="canvases"):
            os.path.join(HERE, "_dist_worker.py"), str(out), str(n_total), str(steps), mode, wire]
     subprocess.run(cmd, check=True, env=env, timeout=600, capture_output=True)
     parts = [np.load(out / f"rank{r}.npz") for r in range(world)]
-    keys = ("x", "y", "th", "w", "idx") + (("maps",) if mode == "slam" else ())
+    keys = ("x", "y", "th", "w", "idx", "avg", "best") + (("maps", "best_map") if mode == "slam" else ())
     return {k: np.concatenate([p[k] for p in parts]) for k in keys}
+
+
+def check_read_out(got, ref, world, n_total, slam=False):
+    """ShardedFilter.summarize() / best() on every rank against the unsharded oracle: slam::average_pose over all
+    particles (slam/util.cpp:66-85, apps/grid_slam.cpp:119) and get_particles().front() (apps/grid_slam.cpp:112: the
+    heaviest particle, ties to the lowest slot, which is where slam/mcl.cpp:236-238's sort puts it on one handle)."""
+    want = orc.average_pose(ref["x"], ref["y"], ref["th"], math=orc.DET)
+    assert got["avg"].shape == (world, 3) and got["best"].shape == (world, 6)
+    for r in range(world):
+        assert np.array_equal(got["avg"][r].view(np.uint64), got["avg"][0].view(np.uint64))     # the same bits on every rank
+        assert np.array_equal(got["best"][r].view(np.uint64), got["best"][0].view(np.uint64))
+    assert np.allclose(got["avg"][0], want, rtol=1e-12, atol=0)    # a different summation order (blocks, then ranks)
+    k = int(np.flatnonzero(ref["w"] == ref["w"].max())[0])
+    bw, slot, rank, bx, by, bth = got["best"][0]
+    assert bw == ref["w"][k] and int(slot) == k and int(rank) == k // (n_total // world)
+    assert (bx, by, bth) == (ref["x"][k], ref["y"][k], ref["th"][k])
+    if slam:
+        for r in range(world):
+            assert np.array_equal(got["best_map"][r], ref["maps"][k])
 
 
 def reference_run(n_total, steps):
@@ -51,6 +70,7 @@ def test_sharded_filter_gloo_matches_unsharded(tmp_path, world, wire):
     assert np.array_equal(got["idx"], ref["idx"])
     for k in ("x", "y", "th", "w"):
         assert np.array_equal(got[k].view(np.uint64), ref[k].view(np.uint64)), k
+    check_read_out(got, ref, world, n_total)
 
 
 def reference_run_slam(n_total, steps):
@@ -83,4 +103,5 @@ def test_sharded_slam_mode_gloo_matches_unsharded(tmp_path, world, wire):
     for k in ("x", "y", "th", "w"):
         assert np.array_equal(got[k].view(np.uint64), ref[k].view(np.uint64)), k
     assert np.array_equal(got["maps"], ref["maps"])
+    check_read_out(got, ref, world, n_total, slam=True)
     assert len(np.unique(ref["maps"].reshape(n_total, -1), axis=0)) > 1  # the canvases do differ

@@ -452,9 +452,9 @@ def test_weights_slam_mode_maps_bit_exact(sa, shape, B, zmax):
 
 
 # ---- K3/K4 resampling -------------------------------------------------------------------------------
-@pytest.mark.parametrize("order", ["blocked", "reference"])
-@pytest.mark.parametrize("N", [1, 2, 64, 65, 4096, 4097, 100000])
-def test_resample_indices_bit_exact(sa, order, N):
+def check_resample_against_the_oracle(sa, order, N):
+    """slam/mcl.cpp:157-203,232-239: running sums (bits), selected indices, sort permutation and the gathered state
+    of ONE resample of N weights against the oracle, in the given summation order."""
     rng = np.random.default_rng(N)
     w = rng.uniform(0, 1, N) ** 6
     w[rng.uniform(size=N) < 0.15] = 0.0
@@ -477,7 +477,12 @@ def test_resample_indices_bit_exact(sa, order, N):
     assert np.array_equal(idx, oidx)
     # the other order selects the same particles (a draw would have to fall between two roundings)
     other, _, _ = orc.resample(w, u, orc.ORDER_REFERENCE if order == "blocked" else orc.ORDER_BLOCKED)
-    assert np.array_equal(idx, other)
+    if N <= 1_000_000:
+        assert np.array_equal(idx, other)
+    else:
+        # the two running sums differ by ~1e-16 sqrt(N) relative at every one of N boundaries, so of N draws about
+        # N^2 x 1e-13 fall between two roundings: dozens at 20 M.  Each order is bit-exact against ITS oracle above.
+        assert np.count_nonzero(idx != other) <= N // 100_000
     # sort: (weight desc, slot asc); state = old[idx[perm]]
     perm = f.last_order()
     assert np.array_equal(perm, orc.sort_order(w[oidx], 0))
@@ -490,6 +495,23 @@ def test_resample_indices_bit_exact(sa, order, N):
     ref_perm = orc.sort_order(w[oidx], 1)  # the reference's unstable std::sort: same multiset, same front
     assert np.array_equal(w[oidx][ref_perm], nw)
     f.close()
+    return np.unique(oidx).size
+
+
+@pytest.mark.parametrize("order", ["blocked", "reference"])
+@pytest.mark.parametrize("N", [1, 2, 64, 65, 4096, 4097, 100000])
+def test_resample_indices_bit_exact(sa, order, N):
+    check_resample_against_the_oracle(sa, order, N)
+
+
+@pytest.mark.parametrize("order,N", [("blocked", 262_145), ("reference", 262_145), ("blocked", 1_000_000), ("reference", 1_000_000),
+                                     ("blocked", 20_000_000)])
+def test_resample_indices_bit_exact_beyond_the_sample_sort(sa, order, N):
+    """The sizes north_star promises bit-exact indices at: 4 levels of the radix-64 running sum (262 145 .. 16.7 M
+    particles) and 5 (20 M: more than 2^24 slots, 25 bisection steps), the sort path taken above 262 144 particles and
+    SLAM_SORT_FULL there.  The strictly sequential order (one thread) is compared up to 1 M."""
+    distinct = check_resample_against_the_oracle(sa, order, N)
+    assert distinct > N // 4
 
 
 @pytest.mark.parametrize("N", [16384, 50001, 100000, 262144])
@@ -1005,9 +1027,9 @@ def test_full_size_config2_properties(sa):
         f.update_weights(ang, dist, 5.0, 500.0, OFFSET)
     wf, ww = fast.weights(), walk.weights()
     assert_bits(wf, ww, "clearance-skipping vs cell-by-cell walk")     # two independent device algorithms agree
-    sub = rng.choice(N, 400, replace=False)                            # oracle on a sample the CPU finishes in seconds
+    sub = rng.choice(N, 4096, replace=False)                           # oracle on a sample its threads finish in a second
     px, py, pth = fast.poses()
-    ow, _ = orc.update_weights(px[sub], py[sub], pth[sub], g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET)
+    ow, _ = orc.update_weights(px[sub], py[sub], pth[sub], g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET, n_threads=16)
     assert_bits(wf[sub], ow, "weights vs oracle sample")
     st = walk.stats()
     assert st["cells_written"] == 0 and 10 * N * B < st["cells_read"] <= 502 * N * B
@@ -1085,6 +1107,95 @@ def test_sharded_filter_matches_single_handle(sa, shards, split):
     ow, _ = orc.update_weights(ox, oy, oth, g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET)
     idx, _, _ = orc.resample(ow, orc.philox_uniforms(seed, 0, 0, N), orc.ORDER_BLOCKED)
     assert_bits(sf.b.f.poses()[0], ox[idx], "ShardedFilter world=1")
+
+
+@pytest.mark.parametrize("mode", ["localization", "slam"])
+def test_sharded_read_out_average_pose_and_best_particle(sa, mode):
+    """What the app reads every frame (apps/grid_slam.cpp:112-119) from a SHARDED filter: slam::average_pose over all
+    particles (slam/util.cpp:66-85) and get_particles().front(), the heaviest particle with its canvas
+    (slam/mcl.cpp:236-238 puts it first on one handle).  Four shards emulated on one device, their summaries combined as
+    the drivers do after the 64-byte all-gather; against the oracle and against ONE sorted handle."""
+    import ctypes
+
+    from slam_amd.dist import HipShard
+
+    rng = np.random.default_rng(77)
+    shards, seed = 4, 0xBE57
+    slam = mode == "slam"
+    N, B = (256, 24) if slam else (4200, 45)
+    n_loc = N // shards
+    if slam:
+        rows = cols = 96
+        free = np.ones((rows, cols), np.int32)
+        free[:3, :] = free[-3:, :] = free[:, :3] = free[:, -3:] = 0
+        g = None
+        true, off, zmax, sd = [48.0, 44.0, 0.3], [0.0, 6.0, 0.0], 40.0, 2.0
+        x, y, th = cloud(rng, N, true[0], true[1], sxy=2.0, sth=0.1, th0=true[2])
+    else:
+        free = orc.load_map("floor_plan")
+        g = (free * 255).astype(np.uint8)
+        rows, cols = g.shape
+        true, off, zmax, sd = [520.0, 280.0, 0.4], OFFSET, 500.0, 5.0
+        x, y, th = cloud(rng, N, true[0], true[1], th0=true[2])
+    ang, dist = orc.make_scan(free, true, off, B, max_dist=zmax)
+    md = sa.capi.MODE_SLAM if slam else sa.capi.MODE_LOCALIZATION
+    single = sa.Filter(N, rows, cols, mode=md, seed=seed)            # SLAM_SORT_FULL: the front is the best particle
+    backs = [HipShard(n_loc, rows, cols, r, shards, 0, seed, mode=md) for r in range(shards)]
+    for r, q in enumerate([single] + [b.f for b in backs]):
+        if not slam:
+            q.set_map(g)
+        sl = slice(0, N) if r == 0 else slice((r - 1) * n_loc, r * n_loc)
+        q.set_poses(x[sl], y[sl], th[sl])
+    maps = np.full((N, rows, cols), 128, np.uint8)
+    for it in range(2):                                               # second pass: the canvases differ between particles
+        for q in [single] + [b.f for b in backs]:
+            q.update_weights(ang, dist, sd, zmax, off)
+        ow, _ = orc.update_weights(x, y, th, maps if slam else g, ang, dist, sd, zmax, off, slam_mode=slam, math=orc.DET)
+    # before any resample: the weights of this pass, particles in their original slots
+    q = np.concatenate([b.f.shard_summary() for b in backs])          # what the all-gather of 8 doubles per rank produces
+    lib = sa.capi.load_library()
+    avg = np.empty(3)
+    bw, slot, rank, loc = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int64()
+    sa.capi.check(lib.slam_shard_summary_combine(sa.capi.ptr(q), shards, sa.capi.ptr(avg), ctypes.byref(bw), ctypes.byref(slot),
+                                                 ctypes.byref(rank), ctypes.byref(loc)), lib)
+    k = int(np.flatnonzero(ow == ow.max())[0])                        # heaviest, lowest slot among equals
+    assert (bits([bw.value])[0], slot.value, rank.value, loc.value) == (bits([ow[k]])[0], k, k // n_loc, k % n_loc)
+    want = orc.average_pose(x, y, th, math=orc.DET)
+    assert np.allclose(avg, want, rtol=1e-12, atol=0)                 # floating-point sums in another order
+    sp = single.average_pose()
+    assert np.allclose(avg, [sp.x, sp.y, sp.theta], rtol=1e-12, atol=0)
+    if slam:
+        assert np.array_equal(backs[rank.value].f.map_of(loc.value), maps[k])
+    # one handle after its sorted resample: its front is the heaviest SELECTED particle; the shards, resampled from the
+    # same gathered state, name the same one
+    import torch
+
+    gathered = torch.cat([b.packed_state() for b in backs])
+    torch.cuda.synchronize()
+    single.resample()
+    for b in backs:
+        if slam:
+            idx = b.shard_select(gathered, shards)
+            want_c = torch.unique(idx)
+            pool = torch.cat([backs[int(o)].pack_maps(want_c[(want_c // n_loc) == o] - o * n_loc) for o in range(shards)])
+            b.clone_maps(pool, torch.searchsorted(want_c, idx))
+        else:
+            b.shard_resample(gathered, shards)
+    q = np.concatenate([b.f.shard_summary() for b in backs])
+    sa.capi.check(lib.slam_shard_summary_combine(sa.capi.ptr(q), shards, sa.capi.ptr(avg), ctypes.byref(bw), ctypes.byref(slot),
+                                                 ctypes.byref(rank), ctypes.byref(loc)), lib)
+    fx, fy, fth = single.poses(0, 1)
+    bx, by, bth = backs[rank.value].f.poses(loc.value, 1)
+    assert bits([bw.value])[0] == bits(single.weights(0, 1))[0]
+    assert (bits(bx)[0], bits(by)[0], bits(bth)[0]) == (bits(fx)[0], bits(fy)[0], bits(fth)[0])
+    assert slot.value == int(single.last_order()[0])                  # the slot the sort moved to the front
+    if slam:
+        assert np.array_equal(backs[rank.value].f.map_of(loc.value), single.map_of(0))
+    sp = single.average_pose()
+    assert np.allclose(avg, [sp.x, sp.y, sp.theta], rtol=1e-12, atol=0)
+    single.close()
+    for b in backs:
+        b.f.close()
 
 
 def test_sharded_systematic_resampling(sa):
@@ -1175,6 +1286,44 @@ def test_eight_shards_of_the_bench_size(sa):
         assert_bits(np.concatenate([b.f.weights() for b in backs]), single.weights(), "weights")
     assert len(np.unique(single.last_indices())) > 1000
     single.close()
+    for b in backs:
+        b.f.close()
+
+
+def test_eight_shards_of_config_3_global_size_against_the_oracle(sa):
+    """BASELINE configs[2]'s resampling at its GLOBAL size: 8 shards x 1.25 M particles (emulated on one device), every
+    shard rebuilding the running sum of all 10 M weights and selecting its own slots (slam/mcl.cpp:157-203).  The
+    concatenated indices and the gathered state against the ORACLE's, not against another handle."""
+    import torch
+
+    from slam_amd.dist import HipShard
+
+    shards, n_loc, seed = 8, 1_250_000, 0x5EED0003
+    N = shards * n_loc
+    rng = np.random.default_rng(83)
+    w = rng.uniform(0, 1, N) ** 6
+    w[rng.uniform(size=N) < 0.15] = 0.0
+    x, y, th = rng.uniform(0, 16, N), rng.uniform(0, 16, N), rng.uniform(-1, 1, N)
+    backs = [HipShard(n_loc, 16, 16, r, shards, 0, seed) for r in range(shards)]
+    for r, b in enumerate(backs):
+        sl = slice(r * n_loc, (r + 1) * n_loc)
+        b.f.set_poses(x[sl], y[sl], th[sl])
+        b.f.set_weights(w[sl])
+    gathered = torch.cat([b.packed_state() for b in backs])      # what all_gather_into_tensor produces
+    torch.cuda.synchronize()
+    for b in backs:
+        b.shard_resample(gathered, shards)
+    oidx, oP, osum = orc.resample(w, orc.philox_uniforms(seed, 0, 0, N), orc.ORDER_BLOCKED)
+    for r, b in enumerate(backs):
+        sl = slice(r * n_loc, (r + 1) * n_loc)
+        assert np.array_equal(b.f.last_indices(), oidx[sl]), f"indices of shard {r}"
+        P, total = b.f.prefix()
+        assert_bits(P, oP, f"running sums of shard {r}")
+        assert bits([total])[0] == bits([osum])[0]
+        px, py, pth = b.f.poses()
+        assert_bits(px, x[oidx[sl]], "x"), assert_bits(py, y[oidx[sl]], "y"), assert_bits(pth, th[oidx[sl]], "theta")
+        assert_bits(b.f.weights(), w[oidx[sl]], "weights")
+    assert np.unique(oidx).size > N // 4
     for b in backs:
         b.f.close()
 
@@ -1369,8 +1518,9 @@ def test_full_shard_sizes_of_configs_3_and_5(sa, size, N, B, zmax, uniform):
     walk.update_weights(ang, dist, 0.5, zmax, OFFSET)
     assert_bits(lw[sub], walk.weights(), "subset recomputed cell by cell")
     walk.close()
-    osub = sub[:24]
-    olw, _ = orc.update_weights(x[osub], y[osub], th[osub], g, ang, dist, 0.5, zmax, OFFSET, math=orc.DET, log_domain=True)
+    osub = rng.permutation(sub)[:2048]   # the threaded oracle walks these ~2 M rays cell by cell in a few seconds
+    olw, _ = orc.update_weights(x[osub], y[osub], th[osub], g, ang, dist, 0.5, zmax, OFFSET, math=orc.DET, log_domain=True,
+                                n_threads=16)
     assert_bits(lw[osub], olw, "subset vs oracle")
     # (both passes know the cloud's extent: the uniform cloud over 16384^2 runs on the wave-per-particle kernel in place
     # order, the Gaussian one on lanes over particles with the heading first)
@@ -1387,6 +1537,12 @@ def test_full_shard_sizes_of_configs_3_and_5(sa, size, N, B, zmax, uniform):
     idx = f.last_indices()
     assert idx.min() >= 0 and idx.max() < N
     assert_bits(f.weights(), lw[idx], "gathered weights")
+    # slam/mcl.cpp:157-203 at the full shard size against the oracle: running sums bit for bit and every selected index
+    # (4 levels of the radix-64 hierarchy; at 12.5 M more than 2^23 slots, 24 bisection steps)
+    oidx, oP, osum = orc.resample(orc.log_domain_weights(lw, orc.DET), orc.philox_uniforms(seed, 0, 0, N), orc.ORDER_BLOCKED)
+    assert_bits(P, oP, "running sums vs oracle")
+    assert bits([total])[0] == bits([osum])[0]
+    assert np.array_equal(idx, oidx), "selected indices vs oracle"
     f.close()
 
 
@@ -1410,7 +1566,7 @@ def test_full_shard_size_of_config_4_grid_slam(sa):
     pool = 16_000_000  # 64 GB: every particle copies the ~40 tiles its scan writes in every pass (clones share tiles again after each resample)
     f = sa.Filter(N, rows, cols, mode=sa.capi.MODE_SLAM, seed=0x5EED4004, sort=sa.capi.SORT_NONE, map_storage=sa.capi.MAPS_TILED,
                   tile_pool_tiles=pool)
-    S, SO = 48, 3
+    S, SO = 64, 64   # per step: 64 particles recomputed by the literal kernel AND by the CPU oracle, canvases included
     small = sa.Filter(S, rows, cols, mode=sa.capi.MODE_SLAM, sort=sa.capi.SORT_NONE, map_storage=sa.capi.MAPS_DENSE,
                       raycaster=sa.capi.RAYCAST_FAST_PARTICLE_LANES)
     small.record_hits(True)
@@ -1436,10 +1592,13 @@ def test_full_shard_size_of_config_4_grid_slam(sa):
         assert_bits(w[sub], small.weights(), f"step {step}: subset recomputed by the literal kernel on dense canvases")
         for k, p in enumerate(sub):
             assert np.array_equal(f.map_of(int(p)), small.map_of(k)), f"step {step}: canvas of particle {p}"
-        ow, oxy, ocell, _ = orc.update_weights(x[sub[:SO]], y[sub[:SO]], th[sub[:SO]], before[:SO].copy(), ang, dist, 5.0, 500.0, OFFSET,
-                                               slam_mode=True, want_hits=True, math=orc.DET)
+        omaps = before[:SO].copy()
+        ow, oxy, ocell, _ = orc.update_weights(x[sub[:SO]], y[sub[:SO]], th[sub[:SO]], omaps, ang, dist, 5.0, 500.0, OFFSET,
+                                               slam_mode=True, want_hits=True, math=orc.DET, n_threads=16)
         assert_bits(w[sub[:SO]], ow, f"step {step}: subset vs oracle")
         assert np.array_equal(small.hits()[1][:SO], ocell)
+        for k in range(SO):   # slam/raycast.cpp:194-214: the canvases the oracle drew = the tiles of the big filter
+            assert np.array_equal(small.map_of(k), omaps[k]), f"step {step}: canvas of particle {sub[k]} vs oracle"
         if step:
             assert (ocell >= 0).any()  # from the second scan on the rays meet the walls the first one drew
         f.resample()

@@ -199,3 +199,75 @@ def test_cpp_rccl_shard_driver_matches_one_handle(tmp_path, exchange):
     f.close()
     assert parts.shape == (n, 4) and np.array_equal(parts, ref)
     assert np.unique(parts[:, 0]).size > 10  # a real cloud, not one collapsed particle
+
+
+def canvas_hash(m):
+    """hash_bytes of tests/host_cpp/shard_rccl.cpp."""
+    v = m.reshape(-1).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        return int(((v + np.uint64(1)) * (np.arange(v.size, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345))).sum(dtype=np.uint64))
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_shard_driver_read_out(tmp_path):
+    """slam::ShardedMCL::average_pose() / best(): slam::average_pose and get_particles().front() across ranks
+    (slam/util.cpp:66-85, apps/grid_slam.cpp:112-119), here through a one-rank communicator: against the oracle on the
+    particles the program printed."""
+    exe = os.path.join(HERE, "host_cpp", "shard_rccl")
+    if not os.path.exists(exe):
+        pytest.skip("shard_rccl absent (make -C tests/host_cpp shard_rccl)")
+    g = (orc.load_map("floor_plan") * 255).astype(np.uint8)
+    raw = tmp_path / "map.u8"
+    g.tofile(raw)
+    n = 3000
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    got = subprocess.run([exe, str(raw), str(g.shape[0]), str(g.shape[1]), str(n), "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert got.returncode == 0, (got.stdout[-500:] + got.stderr[-2000:])
+    lines = got.stdout.splitlines()
+    parts = np.array([[int(t, 16) for t in ln.split()[1:]] for ln in lines if ln.startswith("P ")], dtype=np.uint64).view(np.float64)
+    avg = [float(t) for t in next(ln for ln in lines if ln.startswith("AVG")).split()[1:]]
+    best = next(ln for ln in lines if ln.startswith("BEST ")).split()[1:]
+    assert np.allclose(avg, orc.average_pose(parts[:, 0], parts[:, 1], parts[:, 2], math=orc.DET), rtol=1e-12, atol=0)
+    k = int(np.flatnonzero(parts[:, 3] == parts[:, 3].max())[0])
+    assert (float(best[0]), int(best[1]), int(best[2])) == (parts[k, 3], k, 0)
+    assert [float(t) for t in best[3:]] == parts[k, :3].tolist()
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_shard_driver_slam_mode_matches_one_tiled_handle():
+    """SLAM mode of slam::ShardedMCL (BASELINE configs[3] from the reference's own language): select, request counts and
+    indices, tables + distinct tiles through grouped ncclSend / ncclRecv, import (slam/mcl.cpp:147-155,205-227 across
+    ranks).  One-rank communicator (the sends and receives still go through RCCL) against a plain tiled handle: particles,
+    EVERY canvas, the best particle with its canvas and the mean pose."""
+    import slam_amd as sa
+
+    exe = os.path.join(HERE, "host_cpp", "shard_rccl")
+    if not os.path.exists(exe):
+        pytest.skip("shard_rccl absent (make -C tests/host_cpp shard_rccl)")
+    n, rows, cols, steps = 600, 200, 264, 4
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    got = subprocess.run([exe, "slam", str(rows), str(cols), str(n), str(steps)], env=env, capture_output=True, text=True, timeout=300)
+    assert got.returncode == 0, (got.stdout[-500:] + got.stderr[-2000:])
+    lines = got.stdout.splitlines()
+    parts = np.array([[int(t, 16) for t in ln.split()[1:]] for ln in lines if ln.startswith("P ")], dtype=np.uint64)
+    hashes = [int(ln.split()[2], 16) for ln in lines if ln.startswith("M ")]
+    f = sa.Filter(n, rows, cols, mode=sa.capi.MODE_SLAM, seed=0x5EED0004, sort=sa.capi.SORT_NONE, map_storage=sa.capi.MAPS_TILED)
+    for k in range(steps):
+        b = np.arange(24)
+        ang, dist = b * (2 * np.pi / 24) - np.pi, 12.0 + 2.5 * ((b + 3 * k) % 11)
+        f.predict([0.0, 1.5, 0.01], [0.001] * 4)
+        f.update(ang, dist, 2.0, 40.0, [0.0, 6.0, 0.0])
+    x, y, th = f.poses()
+    w = f.weights()
+    ref = np.stack([x, y, th, w], 1).view(np.uint64)
+    assert parts.shape == (n, 4) and np.array_equal(parts, ref)
+    maps = [f.map_of(k) for k in range(n)]
+    assert hashes == [canvas_hash(m) for m in maps]
+    assert len(set(hashes)) > 5 and np.unique(parts[:, 0]).size > 5     # canvases and particles do differ
+    k = int(np.flatnonzero(w == w.max())[0])
+    best = next(ln for ln in lines if ln.startswith("BEST ")).split()[1:]
+    assert (float(best[0]), int(best[1]), int(best[2])) == (w[k], k, 0) and [float(t) for t in best[3:]] == [x[k], y[k], th[k]]
+    assert int(next(ln for ln in lines if ln.startswith("BESTMAP")).split()[1], 16) == canvas_hash(maps[k])
+    avg = [float(t) for t in next(ln for ln in lines if ln.startswith("AVG")).split()[1:]]
+    assert np.allclose(avg, orc.average_pose(x, y, th, math=orc.DET), rtol=1e-12, atol=0)
+    f.close()

@@ -39,13 +39,19 @@ def static_indices(sa, torch, w, u, resampler, seed=0, step=0, stream=None):
     out = torch.full((n + 8,), -7, dtype=torch.int32, device="cuda")  # 8 guard entries behind the output
     torch.cuda.synchronize()
     st = stream.cuda_stream if stream is not None else None
+    # "allocates nothing" is measured at the DRIVER: hipMemGetInfo's free bytes see a hipMalloc / hipFree made inside
+    # libslam_hip.so, which torch's caching-allocator statistics cannot (slam_static_init ran before: the first call
+    # on a device may load the code object that holds the static array)
+    free_before = torch.cuda.mem_get_info()[0]
     before = torch.cuda.memory_allocated()
     rc = lib.slam_resample_select_static(0, ctypes.c_void_p(st), ctypes.c_void_p(wd.data_ptr()), n, resampler,
                                          ctypes.c_void_p(ud.data_ptr()) if ud is not None else None, seed, step,
                                          ctypes.c_void_p(out.data_ptr()))
     sa.capi.check(rc)
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == free_before, "device memory was allocated or freed inside the call"
     torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before, "device memory was allocated or freed by the call's kernels"
     got = out.cpu().numpy()
     assert np.all(got[n:] == -7), "wrote past idx_dev[n]"
     return got[:n]
@@ -104,3 +110,48 @@ def test_select_static_rejects_sizes_beyond_the_static_array():
     assert rc == -1 and b"SLAM_SELECT_STATIC_MAX" in lib.slam_last_error()
     assert lib.slam_resample_select_static(0, None, ctypes.c_void_p(wd.data_ptr()), 0, 0, None, 0, 0, ctypes.c_void_p(out.data_ptr())) == -1
     assert lib.slam_resample_select_static(0, None, None, 5, 0, None, 0, 0, ctypes.c_void_p(out.data_ptr())) == -1
+
+
+def test_select_static_under_hip_graph_capture():
+    """The caller the entry point exists for: the call recorded into a HIP graph (hipStreamBeginCapture through
+    torch.cuda.graph) and replayed.  An allocation, a free or a synchronisation inside the call would fail the capture;
+    the replayed indices must equal the eager ones, also after the weights behind the captured pointers changed."""
+    import torch
+
+    import slam_amd as sa
+
+    lib = sa.capi.load_library()
+    sa.capi.check(lib.slam_static_init(0))
+    rng = np.random.default_rng(9)
+    n = 70_000
+    w = rng.uniform(0, 1, n) ** 6
+    u = orc.reference_uniforms(n, tick=11)
+    wd = torch.from_numpy(w).cuda()
+    ud = torch.from_numpy(u).cuda()
+    out = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+
+    def call(stream):
+        sa.capi.check(lib.slam_resample_select_static(0, ctypes.c_void_p(stream.cuda_stream), ctypes.c_void_p(wd.data_ptr()), n, 0,
+                                                      ctypes.c_void_p(ud.data_ptr()), 0, 0, ctypes.c_void_p(out.data_ptr())))
+
+    side = torch.cuda.Stream()
+    call(side)                                   # eager, on the stream the capture will use
+    side.synchronize()
+    eager = out.cpu().numpy().copy()
+    assert np.array_equal(eager, orc.resample(w, u, orc.ORDER_BLOCKED)[0])
+    out.fill_(-7)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):   # capture_error_mode "global": any prohibited call made meanwhile fails
+        call(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert np.all(out.cpu().numpy() == -7), "a captured call must not run"
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), eager)
+    # new weights behind the same pointers, replayed: the graph holds no stale scratch contents
+    w2 = rng.uniform(0, 1, n) ** 2
+    wd.copy_(torch.from_numpy(w2))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), orc.resample(w2, u, orc.ORDER_BLOCKED)[0])
