@@ -152,15 +152,26 @@ struct WeightArgs
 // (counts cells).  One wavefront = one particle; lane l takes beams l, l+64, ...; the per-beam
 // log-likelihoods are then added in beam order (slam/mcl.cpp:69-74) so the weight has the
 // reference's rounding.
+enum { K_WEIGHTS_L_MAX_B = 1536 };
+#define K_WEIGHTS_L_LDS(B) ((B) <= slamk::K_WEIGHTS_L_MAX_B ? (size_t)(B) * 40 : (size_t)0)
 template <int VARIANT>
 __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
 {
     // the beams' log-likelihoods wait here for lane 0 to add them in beam order at the end (one dependent add per beam;
-    // adding them group by group took two readlanes per add as well); scans longer than the slab keep the readlane form
-    enum { LW_CAP = 1280 };
-    __shared__ double lw_s[4][LW_CAP];
-    double* lw_mine = lw_s[threadIdx.x >> 6];
-    const bool lw_in_lds = a.B <= LW_CAP;
+    // adding them group by group took two readlanes per add as well); scans longer than the slab keep the readlane form.
+    // VARIANT 0 (round 3): on the clouds this kernel serves (wide ones) nearly every ray ends farther than 4 sigma from its
+    // measured range, where the likelihood is the clamped constant (slam/util.cpp:14-19), yet in lock step all 64 lanes
+    // paid the square root, the quotient, exp and log whenever ONE of them needed them (62 % of the groups at 1.5 % of
+    // the rays).  Now a lane decides "certainly clamped" from squared distances (slam_beam_clamped) and otherwise leaves
+    // the squared hit distance in its slot and its beam number in a list; the listed beams (a dozen of 720) are
+    // evaluated together at the end, 64 at a time, by the same statements (slam_beam_logw_d2).
+    // dynamic LDS (K_WEIGHTS_L_LDS(B) bytes, 0 beyond K_WEIGHTS_L_MAX_B beams): [4 wavefronts][B] doubles, [4][B] beam numbers
+    extern __shared__ __align__(16) unsigned char kwl_lds[];
+    const bool lw_in_lds = a.B <= K_WEIGHTS_L_MAX_B;
+    double* lw_mine = reinterpret_cast<double*>(kwl_lds) + (size_t)(threadIdx.x >> 6) * a.B;
+    unsigned short* todo = reinterpret_cast<unsigned short*>(kwl_lds + (size_t)a.B * 32) + (size_t)(threadIdx.x >> 6) * a.B;
+    const bool defer = VARIANT == 0 && lw_in_lds;
+    int n_todo = 0;  // wave-uniform
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= a.n) return;  // whole wavefront
@@ -188,6 +199,7 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
     {
         const int b = b0 + lane;
         double lw = 0.0;
+        bool later = false;
         if (b < a.B)
         {
             const double theta = pth + a.angles[b] + a.srot;
@@ -204,7 +216,14 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
             else
                 ray_walk<false, true>(a.grid, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, nullptr, nullptr,
                                       a.max_iter, &r, &st);
-            lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps, VARIANT == 0 ? a.inv_stddev : 0.0);
+            if (defer)
+            {
+                const double d2 = slam_beam_d2(&r, sx, sy);
+                later = !slam_beam_clamped(d2, a.z[b], a.zmax, a.clamp4);
+                lw = later ? d2 : a.log_eps;
+            }
+            else
+                lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps, VARIANT == 0 ? a.inv_stddev : 0.0);
             if (a.hit_xy)
             {
                 const size_t o = (size_t)p * a.B + b;
@@ -216,6 +235,12 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
         if (lw_in_lds)
         {
             if (b < a.B) lw_mine[b] = lw;
+            if (defer)
+            {
+                const uint64_t m = __ballot(later);
+                if (later) todo[n_todo + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = (unsigned short)b;
+                n_todo += __builtin_popcountll(m);
+            }
         }
         else
         {
@@ -227,6 +252,17 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (defer && n_todo > 0)
+        {
+            for (int k0 = 0; k0 < n_todo; k0 += 64)
+                if (k0 + lane < n_todo)
+                {
+                    const int b = todo[k0 + lane];
+                    lw_mine[b] = slam_beam_logw_d2(lw_mine[b], a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps, a.inv_stddev);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         if (lane == 0)
             for (int b = 0; b < a.B; ++b) acc += lw_mine[b];  // slam/mcl.cpp:69-74
     }

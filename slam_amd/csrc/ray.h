@@ -531,3 +531,49 @@ DM_HD double slam_beam_logw(const slam_ray_result* r, double sx, double sy, doub
     const double p = norm * dm_exp(-0.5 * (q * q));
     return dm_log(p + 0.1);
 }
+
+// The same likelihood in two steps, for a kernel whose rays are mostly clamped (a wide cloud: k_weights_L<0>).
+// slam_beam_d2: the squared distance origin -> hit as slam_beam_logw forms it (-1: no hit, -2: the search ended at its limit).
+// slam_beam_clamped: true only if slam_beam_logw is CERTAIN to return log_eps (slam/util.cpp:14-19), decided without the
+// square root: with t = z +- clamp, d2 beyond t^2 by a relative 1e-7 puts sqrt(d2) beyond t by 5e-8 t, far more than the
+// roundings of the square root and of the subtraction (2^-52 each) can move xarg across the clamp.  Everything else (the
+// few rays within 4 sigma of their measured range, and a sliver of 1e-7 around it) goes through slam_beam_logw_d2,
+// which is slam_beam_logw from d2 on: same statements, same bits.
+DM_HD double slam_beam_d2(const slam_ray_result* r, double sx, double sy)
+{
+    if (r->hx == -2.0 || r->hx == -1.0) return r->hx;
+    const double ex = r->hx - sx, ey = r->hy - sy;
+    return ex * ex + ey * ey;
+}
+
+DM_HD bool slam_beam_clamped(double d2, double z, double zmax, double clamp)
+{
+    if (d2 == -2.0) return true;
+    if (d2 == -1.0) return dm_fabs(z - zmax) > clamp;  // exact: the very test of slam_beam_logw
+    const double hi = z + clamp, lo = z - clamp;
+    if (d2 > (hi * hi) * 1.0000001) return true;
+    return lo > 0.0 && d2 < (lo * lo) * 0.9999999;
+}
+
+DM_HD double slam_beam_logw_d2(double d2, double z, double zmax, double stddev, double clamp, double norm, double log_eps,
+                               double inv_stddev = 0.0)
+{
+    double xarg;
+    if (d2 == -2.0) return log_eps;
+    if (d2 == -1.0)
+        xarg = z - zmax;
+    else
+        xarg = dm_sqrt(d2) - z;
+    if (dm_fabs(xarg) > clamp) return log_eps;  // slam/util.cpp:14-19
+    double q;
+    if (inv_stddev != 0.0)
+    {
+        const double q0 = xarg * inv_stddev;
+        const double q1 = dm_fma(dm_fma(-q0, stddev, xarg), inv_stddev, q0);
+        q = dm_fma(dm_fma(-q1, stddev, xarg), inv_stddev, q1);
+    }
+    else
+        q = xarg / stddev;
+    const double p = norm * dm_exp(-0.5 * (q * q));
+    return dm_log(p + 0.1);
+}

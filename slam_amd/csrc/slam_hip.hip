@@ -742,12 +742,12 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, h->order_pass++ & 1, h->obox_host);
             h->poses_reset = false;
         }
-        hipLaunchKernelGGL(slamk::k_weights_L<0>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(slamk::k_weights_L<0>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), K_WEIGHTS_L_LDS(B), h->stream, a);
     }
     else
     {
         a.grid = h->grid;
-        hipLaunchKernelGGL(slamk::k_weights_L<1>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(slamk::k_weights_L<1>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), K_WEIGHTS_L_LDS(B), h->stream, a);
     }
     HIPCHK(hipGetLastError());
     return SLAM_OK;

@@ -359,8 +359,11 @@ __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bit
 
 // LDS of one wavefront (dynamic): [512 B update tables][npass x 64 beams x 16 B geometry bits][win_w^2 x 4 B table window]
 // STATS: the counters of slam_mcl_get_stats (cells read, cells written, samples) are kept: about 5 % of the kernel
+#ifndef S2_WAVES
+#define S2_WAVES 4
+#endif
 template <bool TILED, bool STATS = true>
-__global__ void __launch_bounds__(64, 4) k_weights_S2(WeightArgs a, TileArgs ta, int npass, int win_w, int force_literal)
+__global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2(WeightArgs a, TileArgs ta, int npass, int win_w, int force_literal)
 {
     extern __shared__ __align__(16) unsigned char s2_lds[];
     uint8_t* luts = s2_lds;                                // free table, occupied table

@@ -1,6 +1,7 @@
 // ray_harness.cpp — TEST-ONLY host build of the device ray functions in slam_amd/csrc/ray.h.
 // Lets the CPU test-suite check the exact-jump / clearance logic of ray_fast_L against the
 // literal walk without a GPU.  Not shipped, not reachable from libslam_hip.so.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -124,6 +125,61 @@ HH_API void hh_fast_reads(const uint8_t* map, int rows, int cols, long n, const 
         ray_fast_L(Ep.data(), (unsigned)stride, cols + 4, rows, cols, sx[r], sy[r], c, s, zmax2, k_safe, &b, &reads);
         reads_out[r] = (int)reads;
     }
+}
+
+// per-ray number of clearance lookups of a whole weighting pass as the kernels run it (search limited to z + 4 sigma):
+// n particles x B beams, reads_out[p * B + b] (design studies of the lane assignment, tools/lane_sim.py)
+HH_API void hh_pass_reads(const uint8_t* planes, int rows, int cols, long n, const double* px, const double* py, const double* pth,
+                          int B, const double* angles, const double* z, double zmax, double stddev, double sd, double stheta,
+                          double srot, int* reads_out)
+{
+    const double zmax2 = zmax * zmax;
+    int k_safe = (int)__builtin_floor(zmax) - 1;
+    if (k_safe < 0) k_safe = 0;
+    const size_t stride = slam_cone_plane_stride(rows, cols);
+    for (long p = 0; p < n; ++p)
+    {
+        double s0, c0;
+        dm_sincos(pth[p] + stheta, &s0, &c0);
+        const double sx = px[p] + c0 * sd, sy = py[p] + s0 * sd;
+        for (int b = 0; b < B; ++b)
+        {
+            double s, c;
+            dm_sincos(pth[p] + angles[b] + srot, &s, &c);
+            slam_ray_result r;
+            unsigned reads = 0;
+            ray_fast_L(planes, (unsigned)stride, cols + 4, rows, cols, sx, sy, c, s, zmax2, k_safe, &r, &reads, slam_sample_limit(z[b], stddev));
+            reads_out[p * B + b] = (int)reads;
+        }
+    }
+}
+
+// slam_beam_logw against its two-step form (slam_beam_d2 / slam_beam_clamped / slam_beam_logw_d2, what k_weights_L<0>
+// runs): the value must be the same bits for every ray, and a ray declared clamped must really evaluate to log_eps.
+// hx < 0 selects the markers (-1: miss, -2: limit).  Returns the differing rays; *deferred counts the undecided ones.
+HH_API long hh_logw_two_step(long n, const double* hx, const double* hy, const double* sx, const double* sy, const double* z,
+                             double zmax, double stddev, int fast_div, long* deferred)
+{
+    const double clamp = 4.0 * stddev, norm = 1.0 / (stddev * __builtin_sqrt(2 * M_PI)), log_eps = dm_log(0.0 + 0.1);
+    const double inv = fast_div ? 1.0 / stddev : 0.0;
+    long bad = 0;
+    *deferred = 0;
+    for (long r = 0; r < n; ++r)
+    {
+        slam_ray_result res = {hx[r], hy[r], 0};
+        const double want = slam_beam_logw(&res, sx[r], sy[r], z[r], zmax, stddev, clamp, norm, log_eps, inv);
+        const double d2 = slam_beam_d2(&res, sx[r], sy[r]);
+        double got;
+        if (slam_beam_clamped(d2, z[r], zmax, clamp))
+            got = log_eps;
+        else
+        {
+            ++*deferred;
+            got = slam_beam_logw_d2(d2, z[r], zmax, stddev, clamp, norm, log_eps, inv);
+        }
+        if (std::memcmp(&want, &got, 8)) ++bad;
+    }
+    return bad;
 }
 
 // The sample limit of ray_fast_L0 (search only as far as z + 4 sigma): the beam log-likelihood must equal, bit for bit,

@@ -136,6 +136,39 @@ def test_sample_limit_of_the_hit_search_keeps_the_beam_likelihood(hh, name):
     assert total_stopped > 1000  # the limit does end searches
 
 
+def test_beam_likelihood_in_two_steps_equals_the_one_step_form(hh):
+    """slam_beam_clamped decides "beyond 4 sigma" from squared distances (no square root) and may only say so when
+    slam_beam_logw (slam/raycast.cpp:233-241, slam/util.cpp:9-19) returns the clamped value; everything else is evaluated by
+    the same statements from the squared distance.  Rays placed ON the clamp (to the last bits), far from it, misses, limit stops."""
+    rng = np.random.default_rng(44)
+    hh.hh_logw_two_step.restype = ctypes.c_long
+    total_deferred = 0
+    for sigma, zmax in [(5.0, 500.0), (0.5, 4000.0), (0.01, 30.0), (40.0, 100.0), (1e-3, 2.0)]:
+        n = 300000
+        sx, sy = rng.uniform(0, 2000, n), rng.uniform(0, 2000, n)
+        z = rng.uniform(0, zmax, n)
+        z[::9] = zmax
+        z[1::9] = np.minimum(rng.uniform(0, 8 * sigma, z[1::9].size), zmax)   # lo = z - clamp near or below 0
+        # hit distance: anywhere; near z; within a few ulp of z +- 4 sigma
+        d = rng.uniform(0, 1.2 * zmax, n)
+        near = rng.uniform(size=n) < 0.5
+        d[near] = np.abs(z[near] + rng.uniform(-6, 6, near.sum()) * sigma)
+        edge = rng.uniform(size=n) < 0.25
+        d[edge] = np.abs(z[edge] + rng.choice([-4.0, 4.0], edge.sum()) * sigma * (1 + rng.integers(-40, 41, edge.sum()) * 2.0 ** -50))
+        phi = rng.uniform(-np.pi, np.pi, n)
+        hx, hy = sx + d * np.cos(phi), sy + d * np.sin(phi)
+        hx[2::13] = -1.0   # misses
+        hx[3::17] = -2.0   # searches that ended at their limit
+        hy[hx < 0] = hx[hx < 0]
+        for fast_div in (0, 1):
+            dfr = ctypes.c_long()
+            bad = hh.hh_logw_two_step(ctypes.c_long(n), ptr(hx), ptr(hy), ptr(sx), ptr(sy), ptr(z), ctypes.c_double(zmax), ctypes.c_double(sigma),
+                                      fast_div, ctypes.byref(dfr))
+            assert bad == 0, (sigma, zmax, fast_div, bad)
+            total_deferred += dfr.value
+    assert 200000 < total_deferred < 2200000   # both kinds of ray occur
+
+
 def test_quotient_from_the_reciprocal_is_the_correctly_rounded_quotient(hh):
     """slam_beam_logw forms xarg / stddev (slam/util.cpp:11) from RN(1 / stddev) with two correction steps in the
     particle-lane kernel; the result must be the division's, bit for bit: random operands in the range the kernel
