@@ -123,6 +123,57 @@ def source_fingerprint():
     return h.hexdigest()[:16]
 
 
+HBM_MEASURED_GBS = 6290.0   # MI355X_MICROARCH.md: float4 copy, 79 % of the spec
+N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; peak engine clock
+
+
+def physical_roofline(kernel_names, kernel_ms, f64_key):
+    """What the kernel does to the machine, from the committed counter passes (profiles/pmc_weights_kernel.json, taken by
+    profiles/run_profile.sh with rocprofv3 --pmc in runs of their own) and the kernel's duration measured live in THIS run.
+    Quoted only while the kernel sources are the ones the counters were taken from (fingerprint), else None.
+      hbm: measured bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) / duration, as a fraction of 8 TB/s and of 6.29 TB/s;
+      valu: wavefront VALU instructions per launch, weighed with the static share of 64-bit instructions (two issue
+            slots each on gfx950: profiles/valu_f64_share.json), over the issue slots of 1024 SIMDs in that duration."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_weights_kernel.json")))
+        fp = source_fingerprint()
+        if rec.get("source_fingerprint") != fp:
+            return None
+        ks = [rec["kernels"][k] for k in kernel_names]
+        traffic = sum(k["hbm_bytes"] for k in ks)
+        out = {"hbm_bytes_per_launch": traffic, "hbm_gbs": traffic / (kernel_ms * 1e-3) / 1e9}
+        out["hbm_measured_frac"] = out["hbm_gbs"] / HBM_PEAK_GBS
+        out["hbm_frac_of_measured_copy_rate"] = out["hbm_gbs"] / HBM_MEASURED_GBS
+        if all("sq" in k for k in ks):
+            valu = sum(k["sq"]["SQ_INSTS_VALU"] for k in ks)
+            salu = sum(k["sq"]["SQ_INSTS_SALU"] for k in ks)
+            share = None
+            try:
+                sh = json.load(open(os.path.join(ROOT, "profiles", "valu_f64_share.json")))
+                if sh.get("source_fingerprint") == fp:
+                    share = sh["kernels"][f64_key]["f64_share"]
+            except Exception:
+                share = None
+            slots = N_SIMD * CLOCK_HZ * kernel_ms * 1e-3
+            v = {"wave_valu_insts_per_launch": valu, "wave_salu_insts_per_launch": salu, "simd_cycles_available": slots,
+                 "f64_share_static": share, "valu_insts_per_cycle_per_simd": valu / slots}
+            if share is not None:
+                v["issue_slot_frac"] = valu * (1.0 + share) / slots
+                v["note"] = ("issue_slot_frac = VALU wavefront instructions x (1 + 64-bit share) / (1024 SIMDs x 2.4 GHz x kernel time): a 64-bit "
+                             "VALU instruction holds the SIMD for two slots; SALU and memory instructions issue beside it")
+            out["valu"] = v
+        return out
+    except Exception:
+        return None
+
+
+def algorithmic_frac(achieved):
+    """SURVEY.md §8d's figure as a fraction of the 8 TB/s roofline; above 1 it is no fraction of a roofline (the kernel does not
+    read those bytes: the clearance search skips them) and is reported as a ratio of its own."""
+    f = achieved / HBM_PEAK_GBS
+    return (f, None) if f <= 1.0 else (None, f)
+
+
 def slam_scans(sa, free, device, n_beams, true0, n_steps):
     """apps/grid_slam.cpp:144-166: one scan per robot pose while the robot drives straight on (UP key: 2.5 per frame)."""
     poses, (x, y, th) = [], true0
@@ -134,16 +185,17 @@ def slam_scans(sa, free, device, n_beams, true0, n_steps):
 
 def slam_cpu_baseline(scans, rows, cols, n_beams, n=None):
     """CPU oracle in SLAM mode (walk + occupancy update, threaded like slam/mcl.cpp:120-137; resample with the deep
-    copy of slam/mcl.cpp:147-155) on a bounded number of particles: the time of its last step."""
+    copy of slam/mcl.cpp:147-155) on a bounded number of particles: the mean of its last three steps (>= 1 s of work)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as orc
 
     cores = min(16, len(os.sched_getaffinity(0)))
-    n = n or max(cores, min(256, int(3.0e8 // (rows * cols))))  # canvases of the sample within ~300 MB
+    n = n or max(cores, min(4096, int(4.0e9 // (rows * cols))))  # canvases of the sample within ~4 GB (twice that during the copy)
     maps = np.full((n, rows, cols), 128, np.uint8)
     xs, ys, ths = np.full(n, cols / 2.0), np.full(n, rows / 2.0), np.full(n, np.pi / 2)
     odom, alphas = [0.0, 2.5, 0.0], [1e-3] * 4
     steps = min(5, len(scans))
+    times = []
     for k in range(steps):
         xs, ys, ths = orc.predict(xs, ys, ths, odom, alphas, orc.philox_normals(1, k, 0, n))
         t0 = time.perf_counter()
@@ -152,10 +204,12 @@ def slam_cpu_baseline(scans, rows, cols, n_beams, n=None):
         src = idx[orc.sort_order(w[idx], 1)]
         maps = maps[src]
         xs, ys, ths = xs[src], ys[src], ths[src]
-        dt = time.perf_counter() - t0
+        times.append(time.perf_counter() - t0)
+    last = times[-3:]
+    dt = sum(last) / len(last)
     return {"value": n * n_beams / dt, "unit": "particle-beams/s", "cores": cores, "kind": "port",
-            "sample": f"{n} particles x {n_beams} beams with {rows}x{cols} canvases, step {steps} of the same scans "
-                      f"(update + resample with deep copy), {dt:.2f} s, oracle built -Ofast, {cores} threads"}
+            "sample": f"{n} particles x {n_beams} beams with {rows}x{cols} canvases, mean of steps {steps - len(last) + 1}..{steps} of the same scans "
+                      f"(update + resample with deep copy), {dt:.2f} s per step, {sum(last):.2f} s in all, oracle built -Ofast, {cores} threads"}
 
 
 def slam_entry(sa, capi, device, label, n, rows, cols, free, true0, pool, steps, warmup, with_cpu):
@@ -213,13 +267,15 @@ def slam_entry(sa, capi, device, label, n, rows, cols, free, true0, pool, steps,
         "warmup": warmup, "dtype": "f64 positions / u8 cells",
         "instrumentation": "cell counters (slam_mcl_get_stats) off in the timed steps, on in the steps kernel_avg_ms and the bytes come from",
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "k_weights_S2<tiled> (the planned copy-on-write tile copies = the deferred map clone, "
+                     "traffic": traffic, "physical": physical_roofline(["k_weights_S2 (125 000-particle shard)"], w_ms, "k_weights_S2<tiled>") if n == 125_000 else None,
+                     "kernel": "k_weights_S2<tiled> (the planned copy-on-write tile copies = the deferred map clone, "
                                                    "then walk + occupancy update + beam likelihood)", "kernel_avg_ms": w_ms,
                      "algorithmic_bytes_per_launch": alg / extra, "cells_read_per_ray": reads / extra / (n * B),
                      "cells_written_per_ray": writes / extra / (n * B),
                      "note": "bytes = cells read + cells written (counted by the kernel) + 40 B per particle; the kernel also makes "
-                             "the particle's tile copies (4 KiB per tile its scan can write: they are no algorithmic bytes) and its walk "
-                             "is instruction-issue bound (DESIGN.md): this fraction is reported, not claimed"},
+                             "the particle's tile copies (4 KiB per tile its scan can write: they are no algorithmic bytes).  What binds is "
+                             "the memory system under that copy traffic (physical.hbm_*): the kernel's time does not move between 2 and 8 "
+                             "wavefronts per SIMD nor with its geometry phase moved to another kernel (DESIGN.md §6c)"},
         "kernel_ms_per_step": {g: v[0] / max(extra, 1) for g, v in kms.items()},
         "host_enqueue_ms_per_step": host_ms,
         "tiles": tiles,
@@ -293,18 +349,73 @@ def localization_shard_entry(sa, capi, device, label, size, n, B, zmax, uniform,
         "scan": {"range_mean": float(dist.mean()), "range_median": float(np.median(dist)), "beams_at_max_dist": int((dist >= zmax).sum()),
                  "note": "the cost of a pass on a wide cloud depends on the scan: a particle's search ends at its hit or at z + 4 sigma; "
                          "scans from open places of the same grid are up to 5x slower (DESIGN.md, tools/uniform_time.py)"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "weighting pass (k_order_keys + sort + k_rays_pl [+ k_sum_lw])", "kernel_avg_ms": w_ms,
+        "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_frac(achieved)[0],
+                     "algorithmic_over_hbm_peak": algorithmic_frac(achieved)[1],
+                     "traffic": traffic,
+                     "physical": physical_roofline(["weighting kernel of the 16384^2 shard (k_weights_L<0>, 12.5 M particles)"], w_ms, "k_weights_L<0>") if size == 16384 else None,
+                     "kernel": "weighting pass (k_order_keys + order sort + k_rays_pl, or k_weights_L<0> on a sparse cloud)", "kernel_avg_ms": w_ms,
                      "algorithmic_bytes_per_launch": alg, "cells_per_ray_reference_walk": sbar,
-                     "note": "algorithmic, reference-equivalent bytes (cells the reference's walk reads, from 4096 particles on the "
-                             "cell-by-cell kernel); the clearance search reads far fewer"},
+                     "note": "achieved = ALGORITHMIC, reference-equivalent bytes (cells the reference's walk reads, from 4096 particles on the "
+                             "cell-by-cell kernel) over the kernel time, as SURVEY.md §8d defines it; the clearance search reads a few bytes per "
+                             "ray instead, so the figure can exceed the HBM peak (then frac is null and the ratio is algorithmic_over_hbm_peak). "
+                             "What binds is f64 instruction issue: physical.valu"},
+    }
+
+
+def floor_plan_wide_entry(sa, capi, device, n, B, steps):
+    """The headline map and scan with the cloud the headline STARTS from: Gaussian, sigma 25 cells / 0.2 rad around the true
+    pose, never resampled (predict + weighting pass per step).  The headline's own cloud has collapsed onto the pose after
+    its warm-up resamples (config.cloud): this entry is the same kernel chain on rays that do not share their cells."""
+    import torch
+
+    free = load_free_grid("floor_plan")
+    grid = (free * 255).astype(np.uint8)
+    ang, dist = synth_scan(sa, free, device, B)
+    f = sa.Filter(n, *grid.shape, device=device, seed=SEED, sort=capi.SORT_NONE, async_launch=True)
+    f.set_map(grid)
+    f.seed_gaussian(TRUE_POSE, [25.0, 25.0, 0.2])
+    f.update_weights(ang, dist, STDDEV, MAX_DIST, OFFSET)
+    f.synchronize()
+    f.profile(2)
+    f.kernel_ms()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        f.update_weights(ang, dist, STDDEV, MAX_DIST, OFFSET)
+    f.synchronize()
+    ms_step = (time.perf_counter() - t0) / steps * 1e3
+    kms = f.kernel_ms()
+    x, y, th = f.poses()
+    f.close()
+    wk = sa.Filter(n, *grid.shape, device=device, raycaster=capi.RAYCAST_WALK, sort=capi.SORT_NONE)
+    wk.set_map(grid)
+    wk.set_poses(x, y, th)
+    wk.update_weights(ang, dist, STDDEV, MAX_DIST, OFFSET)
+    sbar = wk.stats()["cells_read"] / float(n * B)
+    wk.close()
+    torch.cuda.synchronize()
+    w_ms = kms["weights"][0] / max(kms["weights"][1], 1)
+    alg = n * B * sbar + 40.0 * n + 16.0 * B
+    achieved = alg / (w_ms * 1e-3) / 1e9
+    return {
+        "workload": f"BASELINE configs[1] map and scan, the cloud before any resample: {n} particles x {B} beams, Gaussian sigma 25 cells / 0.2 rad "
+                    "around the true pose, one weighting pass per step (no resample: the cloud stays wide)",
+        "value": n * B / (ms_step * 1e-3), "unit": "particle-beams/s", "ms_per_step": ms_step, "steps": steps, "dtype": "f64",
+        "cloud": {"std_x": float(np.std(x)), "std_y": float(np.std(y)), "std_theta": float(np.std(th))},
+        "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_frac(achieved)[0],
+                     "algorithmic_over_hbm_peak": algorithmic_frac(achieved)[1], "traffic": None,
+                     "kernel": "weighting pass = k_order_keys + order sort + k_rays_pl + k_sum_lw", "kernel_avg_ms": w_ms,
+                     "algorithmic_bytes_per_launch": alg, "cells_per_ray_reference_walk": sbar,
+                     "note": "algorithmic, reference-equivalent bytes over the kernel time (SURVEY.md §8d); binds on f64 instruction issue and, "
+                             "unlike the headline's collapsed cloud, on the spread of trip counts inside a wavefront"},
     }
 
 
 def secondary_entries(sa, capi, device, with_cpu):
     """Configurations next to the headline one (BASELINE configs[0], [3], [2], [4] at one GPU's share)."""
     out = []
-    want = os.environ.get("BENCH_SECONDARY", "slam1k,slam125k,loc8192,loc16384").split(",")
+    want = os.environ.get("BENCH_SECONDARY", "wide100k,slam1k,slam125k,loc8192,loc16384").split(",")
+    if "wide100k" in want:
+        out.append(floor_plan_wide_entry(sa, capi, device, 100_000, 360, 10))
     if "slam1k" in want:
         out.append(slam_entry(sa, capi, device,
                               "BASELINE configs[0] shape on the GPU: grid-SLAM (slam::MCL), assets/map.png scans, 1000 particles x 90 beams, "
@@ -441,6 +552,14 @@ def main():
     f.profile(False)
 
     if rank == 0:
+        # how collapsed the timed cloud is: ancestors of the last resample and the spread of the poses
+        last_idx = f.last_indices()
+        cx, cy, cth = f.poses()
+        cloud_stats = {"unique_ancestors_last_resample": int(np.unique(last_idx).size), "particles": int(n_loc),
+                       "std_x_cells": float(np.std(cx)), "std_y_cells": float(np.std(cy)), "std_theta_rad": float(np.std(cth)),
+                       "note": "after the warm-up and timed resamples (sigma 5, 360 beams) the cloud has converged onto the pose: the rays of "
+                               "a wavefront share their cells, the best case for the ray kernel; secondary[0] is the same chain on the "
+                               "un-resampled sigma-25 cloud"}
         sbar1 = measure_sbar()
         sbar = 0.5 * (sbar0 + sbar1)
         ms_step = elapsed / args.steps * 1e3
@@ -478,12 +597,13 @@ def main():
                 "workload": f"BASELINE configs[1]: MCL localization, floor_plan 1297x599, {n_loc} particles x {B} beams per GPU, "
                             f"max_dist {MAX_DIST:g}, sigma {STDDEV:g}, full step = predict + update (weights, running sum, "
                             f"multinomial select, {'' if sharded else 'sort, '}gather)",
-                "particles_per_gpu": n_loc, "beams": B, "map": "floor_plan", "noise": "philox4x32-10",
+                "particles_per_gpu": n_loc, "beams": B, "map": "floor_plan", "noise": "philox4x32-10", "cloud": cloud_stats,
                 "resampling": "multinomial (reference rule)" + (", global over all ranks via one all-gather" if sharded else ""),
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": algorithmic_frac(achieved)[0], "algorithmic_over_hbm_peak": algorithmic_frac(achieved)[1], "traffic": traffic,
+                "physical": physical_roofline(["k_rays_pl", "k_sum_lw"], k_avg_ms, "k_rays_pl"),
                 "note": "achieved/frac are ALGORITHMIC, reference-equivalent bytes (cells the reference's walk would read, SURVEY.md §8d) "
                         "over the kernel time; the clearance search reads far fewer bytes and the binding limit is VALU issue (DESIGN.md §6)",
                 "kernel": "weighting pass = k_order_keys + pose-coherent order (sample sort, 4 launches) + k_rays_pl + k_sum_lw (raycast + beam likelihood)", "kernel_avg_ms": k_avg_ms,

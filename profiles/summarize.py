@@ -154,6 +154,23 @@ def weights_traffic(base):
     if fk is not None and wk is not None and big and big > 100_000_000:
         out["kernels"]["weighting kernel of the 16384^2 shard (k_weights_L<0>, 12.5 M particles)"] = {
             "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes": 2.0 * fk * 1024.0 + wk * 1024.0}
+    # instruction issue (round 3): wavefront-level VALU / SALU instruction counts and wavefronts per launch of the same kernels,
+    # from the SQ pass; bench.py turns them into an issue-slot fraction with the kernel's measured duration
+    sq = glob.glob(os.path.join(base, "pmc_sq", "*_results.db"))
+    if sq:
+        def sq_of(like, big_only=False):
+            cur = sqlite3.connect(sq[0]).cursor()
+            cond, args = "kernel_name like ?", [like]
+            if big_only:
+                big = cur.execute("select max(grid_size) from counters_collection where kernel_name like ?", (like,)).fetchone()[0]
+                cond, args = cond + " and grid_size=?", args + [big]
+            return {c: float(a) for c, a in cur.execute(f"select counter_name, avg(value) from counters_collection where {cond} group by counter_name", args)}
+        for name, like, big in (("k_rays_pl", "%k_rays_pl<5, false, false>%", False), ("k_sum_lw", "%k_sum_lw%", False),
+                                ("k_weights_S2 (125 000-particle shard)", "%k_weights_S2%", True),
+                                ("weighting kernel of the 16384^2 shard (k_weights_L<0>, 12.5 M particles)", "%k_weights_L<0>%", True)):
+            v = sq_of(like, big)
+            if v and name in out["kernels"]:
+                out["kernels"][name]["sq"] = {k: v[k] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES") if k in v}
     # bench.py quotes hbm_bytes_per_launch only while the kernel sources are the ones measured here
     import hashlib
     h = hashlib.sha256()

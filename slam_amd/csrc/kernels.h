@@ -352,14 +352,16 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     if (DIRECT && real) a.w[p] = a.log_domain ? acc : dm_exp(acc);
 }
 
-// The cloud's bounding box from its first 256 particles into box[which] (see k_order_keys): launched before the first
+// The cloud's bounding box from 256 of its particles into box[which] (see k_order_keys): launched before the first
 // weighting pass after the poses were set or seeded, so that even that pass is ordered for the cloud it meets.
 // box_host: the same four numbers in pinned host memory (a store over PCIe, nobody waits for it): the host reads them
 // some passes later to choose the kernel SHAPE for the cloud (do_weights).
 __global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, const double* y, int* box, int which, int* box_host)
 {
     __shared__ int part[4][4];
-    const int64_t p = threadIdx.x;
+    // 256 particles spread evenly over the index range (after a sorted resample the FIRST 256 are the heaviest particles,
+    // clustered however wide the cloud is; a caller that sets poses in place order has one corner there)
+    const int64_t p = n > 256 ? (int64_t)(((unsigned long long)threadIdx.x * (unsigned long long)n) >> 8) : (int64_t)threadIdx.x;
     int lx = 0x7fffffff, ly = 0x7fffffff, hx = -0x7fffffff - 1, hy = -0x7fffffff - 1;
     if (p < n)
     {
@@ -387,8 +389,7 @@ __global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, c
         cur[1] = min(min(part[0][1], part[1][1]), min(part[2][1], part[3][1]));
         cur[2] = max(max(part[0][2], part[1][2]), max(part[2][2], part[3][2]));
         cur[3] = max(max(part[0][3], part[1][3]), max(part[2][3], part[3][3]));
-        if (box_host)
-            for (int k = 0; k < 4; ++k) box_host[k] = cur[k];
+        if (box_host) *reinterpret_cast<int4*>(box_host) = make_int4(cur[0], cur[1], cur[2], cur[3]);  // one 16-byte store: never torn
     }
 }
 
@@ -424,8 +425,8 @@ __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, 
         }
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // The cloud's extent chooses the order (wide_mode != 0): `box` holds two bounding boxes {xmin, ymin, xmax, ymax} in
-    // cells; this pass reads the one the pass before it wrote and workgroup 0 writes the other from its 256 particles (a
-    // sample: the particle order is the weight order, which knows nothing of place; no atomics: 1563 wavefronts updating
+    // cells; this pass reads the one the pass before it wrote and workgroup 0 writes the other from 256 particles spread over the index
+    // range (a sample; no atomics: 1563 wavefronts updating
     // one cache line cost 110 us; no launch, no host round trip; the choice lags the cloud by one step, which an
     // ordering heuristic may).  Heading first is best while the part of the planes the cloud can reach stays in the
     // caches; a cloud spread over more than 2^22 cells (eight planes: 32 MB = all L2) is ordered by place first (Morton
@@ -440,10 +441,11 @@ __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, 
         {
             __shared__ int part[4][4];
             int lx = 0x7fffffff, ly = 0x7fffffff, hx = -0x7fffffff - 1, hy = -0x7fffffff - 1;
-            if (p < n)
+            const int64_t ps = n > 256 ? (int64_t)(((unsigned long long)threadIdx.x * (unsigned long long)n) >> 8) : p;  // (as k_order_box)
+            if (ps < n)
             {
-                lx = hx = slam_f2i(x[p]);
-                ly = hy = slam_f2i(y[p]);
+                lx = hx = slam_f2i(x[ps]);
+                ly = hy = slam_f2i(y[ps]);
             }
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1)
@@ -466,8 +468,7 @@ __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, 
                 cur[1] = min(min(part[0][1], part[1][1]), min(part[2][1], part[3][1]));
                 cur[2] = max(max(part[0][2], part[1][2]), max(part[2][2], part[3][2]));
                 cur[3] = max(max(part[0][3], part[1][3]), max(part[2][3], part[3][3]));
-                if (box_host)  // (see k_order_box)
-                    for (int k = 0; k < 4; ++k) box_host[k] = cur[k];
+                if (box_host) *reinterpret_cast<int4*>(box_host) = make_int4(cur[0], cur[1], cur[2], cur[3]);  // (see k_order_box)
             }
         }
     }

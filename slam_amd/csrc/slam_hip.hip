@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <emmintrin.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -144,6 +146,7 @@ struct slam_mcl
     size_t hit_cap = 0;
     unsigned long long* stats = nullptr;
     double* partials = nullptr;
+    bool sparse_last = false;  // the kernel shape the last pass chose from the cloud's box (hysteresis)
     double* lw = nullptr;  // scratch of the particle-lane weight kernels
     size_t lw_cap = 0;     // doubles
     uint32_t *okeys = nullptr, *okeys2 = nullptr;  // pose-coherent order of the particle-lane kernels
@@ -495,9 +498,18 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     bool sparse_cloud = false;
     if (!slam_mode && h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096 && h->obox_host && tuning().beam_cells > 0)
     {
-        const volatile int* bx = h->obox_host;
+        // (the device writes the four numbers as one 16-byte store; one 16-byte load here: never a mix of two passes)
+        int bx[4];
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(bx), _mm_load_si128(reinterpret_cast<const __m128i*>(h->obox_host)));
         const int x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
-        if (x1 >= x0 && y1 >= y0) sparse_cloud = ((double)x1 - x0 + 1.0) * ((double)y1 - y0 + 1.0) > (double)tuning().beam_cells * (double)h->n;
+        if (x1 >= x0 && y1 >= y0)
+        {
+            // hysteresis: the shape changes above beam_cells cells per particle and changes back below three quarters of it,
+            // so that a cloud near the threshold does not flip between the kernels from pass to pass
+            const double cells = ((double)x1 - x0 + 1.0) * ((double)y1 - y0 + 1.0), per = (double)tuning().beam_cells * (double)h->n;
+            sparse_cloud = cells > (h->sparse_last ? 0.75 * per : per);
+        }
+        h->sparse_last = sparse_cloud;
     }
     const bool particle_lanes = !slam_mode && (h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES ||
                                                h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT ||
@@ -1164,12 +1176,14 @@ SLAM_API int slam_mcl_set_map_u8(slam_mcl* h, const uint8_t* map, int32_t rows, 
     // the 8 cone-clearance planes with their frames, or ONE Chebyshev plane (a map too large for 32-bit plane offsets;
     // SLAM_CONE_PLANES=0 forces it: tests)
     const bool cone = slam_cone_planes_fit(rows, cols) && tuning().cone_planes;
-    h->clr_stride = cone ? slam_cone_plane_stride(rows, cols) : 0;
-    const size_t pbytes = cone ? 8 * h->clr_stride : (size_t)(rows + 4) * (size_t)(cols + 4);
-    if (!h->grid)
-    {
-        if ((rc = dev_alloc(&h->grid, bytes)) || (rc = dev_alloc(&h->clr, pbytes))) return rc;
-    }
+    const size_t stride = cone ? slam_cone_plane_stride(rows, cols) : 0;
+    const size_t pbytes = cone ? 8 * stride : (size_t)(rows + 4) * (size_t)(cols + 4);
+    // each buffer under its own test: a call that failed between the two allocations leaves a state the next call completes
+    // (the plane layout is the same for every call on a handle: the map size is fixed at create and the tuning is read once)
+    if (!h->grid && (rc = dev_alloc(&h->grid, bytes))) return rc;
+    if (!h->clr && (rc = dev_alloc(&h->clr, pbytes))) return rc;
+    h->clr_stride = stride;  // only once both buffers exist
+    h->have_map = false;     // until the planes below are complete
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->grid, map, bytes, hipMemcpyHostToDevice));
     if (cone && tuning().cone_build)

@@ -48,6 +48,13 @@ public:
     T& at(int i, int j) { return reinterpret_cast<T*>(buf_->data())[static_cast<size_t>(i) * cols + j]; }
     template <class T>
     const T& at(int i, int j) const { return reinterpret_cast<const T*>(buf_->data())[static_cast<size_t>(i) * cols + j]; }
+    // row pointers, as cv::Mat has them (the shim reads and writes matrices row by row: a real cv::Mat may be a view
+    // whose rows are not adjacent in memory)
+    template <class T>
+    T* ptr(int i) { return reinterpret_cast<T*>(buf_->data()) + static_cast<size_t>(i) * cols; }
+    template <class T>
+    const T* ptr(int i) const { return reinterpret_cast<const T*>(buf_->data()) + static_cast<size_t>(i) * cols; }
+    bool isContinuous() const { return true; }
     unsigned char* data() { return buf_ ? buf_->data() : nullptr; }
     const unsigned char* data() const { return buf_ ? buf_->data() : nullptr; }
     Mat clone() const

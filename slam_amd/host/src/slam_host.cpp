@@ -110,47 +110,59 @@ Pose MCL::sensor_position(const Pose& frame_position, const Pose& scanner_offset
 }
 
 #ifndef SLAM_SHIM_REFERENCE_UTIL  // inside the reference's tree its own util.cpp defines these
-// ---- caller-side helpers (single pose, host) -------------------------------------------------------
+// ---- caller-side scalar helpers of slam/util.h:13-27 (declared there; the values are those of slam/util.cpp:9-51) ----
+namespace
+{
+constexpr double kTurn = 2 * M_PI;
+
+// The reference draws every sample from an engine it has just re-seeded from the wall clock (slam/util.cpp:29-30,38-39):
+// one helper does the seeding, the two samplers differ only in what they draw from it.
+std::default_random_engine& engine_seeded_from_the_clock()
+{
+    static thread_local std::default_random_engine engine;
+    engine.seed(std::chrono::system_clock::now().time_since_epoch().count());
+    return engine;
+}
+}  // namespace
+
 double normalize_angle(double angle)
 {
-    angle = std::fmod(angle, 2 * M_PI);
-    if (angle > M_PI) angle -= 2 * M_PI;
-    return angle;
+    const double wrapped = std::fmod(angle, kTurn);  // (-2 pi, 2 pi); only the upper half turn is folded down
+    return wrapped > M_PI ? wrapped - kTurn : wrapped;
 }
 
-// slam/util.cpp:9-43, host scalars
 double pdf_normal_distribution(double stddev, double x)
 {
-    return (1.0 / (stddev * std::sqrt(2 * M_PI))) * std::exp(-0.5 * std::pow(x / stddev, 2));
+    const double peak = 1.0 / (stddev * std::sqrt(kTurn)), in_sigmas = x / stddev;
+    return peak * std::exp(-0.5 * std::pow(in_sigmas, 2));
 }
 
 double pdf_normal_distribution_clamp(double stddev, double x, double multiple_stddev)
 {
-    if (std::fabs(x) > multiple_stddev * stddev) return 0;
-    return pdf_normal_distribution(stddev, x);
+    const bool beyond = std::fabs(x) > multiple_stddev * stddev;
+    return beyond ? 0 : pdf_normal_distribution(stddev, x);
 }
 
 double pdf_triangular_distribution(double stddev, double x)
 {
-    const double variance = std::pow(stddev, 2);
-    return std::max(0.0, 1 / std::sqrt(6 * variance) - std::fabs(x) / 6 / variance);
+    const double var = std::pow(stddev, 2);
+    const double tent = 1 / std::sqrt(6 * var) - std::fabs(x) / 6 / var;
+    return std::max(0.0, tent);
 }
 
 double sample_normal_distribution(double stddev)
 {
-    static thread_local std::default_random_engine generator;
-    generator.seed(std::chrono::system_clock::now().time_since_epoch().count());
-    std::normal_distribution<double> distribution(0, stddev);
-    return distribution(generator);
+    std::normal_distribution<double> gauss(0, stddev);
+    return gauss(engine_seeded_from_the_clock());
 }
 
 double sample_triangular_distribution(double stddev)
 {
-    static thread_local std::default_random_engine generator;
-    generator.seed(std::chrono::system_clock::now().time_since_epoch().count());
-    std::uniform_real_distribution<double> distribution(-stddev, stddev);
-    const double first = distribution(generator);
-    return std::sqrt(6) / 2 * first + distribution(generator);
+    std::default_random_engine& engine = engine_seeded_from_the_clock();  // ONE seeding, two draws
+    std::uniform_real_distribution<double> flat(-stddev, stddev);
+    const double a = flat(engine);
+    const double b = flat(engine);
+    return std::sqrt(6) / 2 * a + b;
 }
 
 #endif
@@ -183,15 +195,15 @@ Pose sample_motion_model_velocity(const Velocity& vel, const Pose& pose, double 
 #ifndef SLAM_SHIM_REFERENCE_UTIL
 Pose average_pose(const std::vector<Particle>& particles)
 {
-    double ax = 0, ay = 0, tx = 0, ty = 0;
-    for (const Particle& p : particles)
+    // slam/util.cpp:66-85: arithmetic mean of the positions, direction of the summed unit headings; sums in particle order
+    double sum[4] = {0, 0, 0, 0};  // x, y, cos, sin
+    for (const Particle& each : particles)
     {
-        ax += p.pose.x;
-        ay += p.pose.y;
-        tx += std::cos(p.pose.theta);
-        ty += std::sin(p.pose.theta);
+        const double term[4] = {each.pose.x, each.pose.y, std::cos(each.pose.theta), std::sin(each.pose.theta)};
+        for (int q = 0; q < 4; ++q) sum[q] += term[q];
     }
-    return {ax / particles.size(), ay / particles.size(), std::atan2(ty, tx)};
+    const double count = particles.size();
+    return {sum[0] / count, sum[1] / count, std::atan2(sum[3], sum[2])};
 }
 
 #endif
@@ -216,13 +228,19 @@ struct MapCache
 template <class T, class F>
 slam_map* resident(MapCache& c, const cv::Mat& m, int kind, F to_u8)
 {
-    const size_t n = static_cast<size_t>(m.rows) * m.cols;
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(&m.at<T>(0, 0));
+    const size_t n = static_cast<size_t>(m.rows) * m.cols, row_bytes = static_cast<size_t>(m.cols) * sizeof(T);
+    if (m.rows <= 0 || m.cols <= 0) throw std::invalid_argument("slam shim: empty matrix");
+    // row by row through ptr(i): a cv::Mat may be a view (ROI) whose rows are not adjacent in memory
     const bool same_shape = c.map && c.rows == m.rows && c.cols == m.cols && c.elem == (int)sizeof(T) && c.kind == kind;
-    if (same_shape && c.source.size() == n * sizeof(T) && std::memcmp(c.source.data(), src, n * sizeof(T)) == 0) return c.map;
+    bool same = same_shape && c.source.size() == n * sizeof(T);
+    for (int i = 0; same && i < m.rows; ++i) same = std::memcmp(c.source.data() + i * row_bytes, m.ptr<T>(i), row_bytes) == 0;
+    if (same) return c.map;
     std::vector<uint8_t> u8(n);
     for (int i = 0; i < m.rows; ++i)
-        for (int j = 0; j < m.cols; ++j) u8[static_cast<size_t>(i) * m.cols + j] = to_u8(m.at<T>(i, j));
+    {
+        const T* row = m.ptr<T>(i);
+        for (int j = 0; j < m.cols; ++j) u8[static_cast<size_t>(i) * m.cols + j] = to_u8(row[j]);
+    }
     if (same_shape)
         check(slam_map_upload(c.map, u8.data()), "slam_map_upload");
     else
@@ -235,11 +253,12 @@ slam_map* resident(MapCache& c, const cv::Mat& m, int kind, F to_u8)
     c.cols = m.cols;
     c.elem = sizeof(T);
     c.kind = kind;
-    c.source.assign(src, src + n * sizeof(T));
+    c.source.resize(n * sizeof(T));
+    for (int i = 0; i < m.rows; ++i) std::memcpy(c.source.data() + i * row_bytes, m.ptr<T>(i), row_bytes);
     return c.map;
 }
 
-thread_local MapCache g_lidar_map, g_raycast_map[3];
+thread_local MapCache g_lidar_map, g_raycast_map[3], g_canvas_map;
 }  // namespace
 
 std::vector<Pose> FakeLidar::scan(const cv::Mat& map, const Pose& pose) const
@@ -291,21 +310,23 @@ Pose raycast<int>(const cv::Mat& map, const Pose& pose, double max2, double step
     return raycast_one<int>(g_raycast_map[2], map, pose, max2, step, 2, [](int v) { return static_cast<uint8_t>(v ? 1 : 0); });
 }
 
-// slam/raycast.cpp:143-223 on the caller's canvas: uploaded, walked and updated on the GPU, read back.
-// (One ray per call, as the reference's signature has it: a caller with many rays for one canvas
-// should hand them to slam_map_raycast_mapping in one call; the filter's own path is MCL::update.)
+// slam/raycast.cpp:143-223 on the caller's canvas: walked and updated on the GPU, read back.  The canvas stays resident
+// between calls (one handle per thread): consecutive rays on one particle's map, which is how slam/mcl.cpp:69-74 calls
+// this, upload nothing (the host copy kept at the last download equals the caller's bytes) and each call costs one
+// launch and one download.  (A caller with many rays for one canvas should hand them to slam_map_raycast_mapping in one
+// call; the filter's own path is MCL::update.)
 Pose raycast_mapping(Particle& particle, double z_squared, double z_max_squared, double step_size)
 {
     cv::Mat& canvas = particle.map;
-    unsigned char* bytes = &canvas.at<unsigned char>(0, 0);
-    slam_map* m = nullptr;
-    check(slam_map_create(shim_device(), bytes, canvas.rows, canvas.cols, &m), "slam_map_create");
+    if (canvas.type() != CV_8UC1) throw std::invalid_argument("slam::raycast_mapping: the canvas must be CV_8UC1 (slam/mcl.cpp:30)");
+    slam_map* m = resident<unsigned char>(g_canvas_map, canvas, 3, [](unsigned char v) { return v; });
     const double p3[3] = {particle.pose.x, particle.pose.y, particle.pose.theta};
     double hit[2] = {-1, -1};
-    int rc = slam_map_raycast_mapping(m, p3, &z_squared, 1, z_max_squared, step_size, hit);
-    if (rc == SLAM_OK) rc = slam_map_download(m, bytes);
-    slam_map_destroy(m);
-    check(rc, "slam_map_raycast_mapping");
+    check(slam_map_raycast_mapping(m, p3, &z_squared, 1, z_max_squared, step_size, hit), "slam_map_raycast_mapping");
+    // the updated canvas back into the caller's matrix, row by row, and into the cache's picture of it
+    std::vector<unsigned char>& now = g_canvas_map.source;
+    check(slam_map_download(m, now.data()), "slam_map_download");
+    for (int i = 0; i < canvas.rows; ++i) std::memcpy(canvas.ptr<unsigned char>(i), now.data() + static_cast<size_t>(i) * canvas.cols, canvas.cols);
     return {hit[0], hit[1], particle.pose.theta};
 }
 
