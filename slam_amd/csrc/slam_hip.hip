@@ -264,7 +264,66 @@ const Tuning& tuning()
 }
 
 // The sample sort serves the sizes at which rocPRIM's sort is a chain of launch-bound merge passes.
-bool use_sample_sort(const slam_mcl* h, int which) { return h->ss_tmp && (tuning().sort_impl & which) && h->n >= sortk::MIN_N && h->n <= sortk::MAX_N; }
+
+// The two sorts of a step (which = 1: particles by weight, slam/mcl.cpp:232-239; 2: the pose-coherent order of the ray kernels),
+// all sizes on the library's own kernels (sortk.h): one workgroup up to 4096 pairs, the sample sort up to 262 144, the radix
+// sort beyond.  rocPRIM stays behind SLAM_SORT_IMPL (bit cleared) as the sort the tests compare these with; its scratch is
+// allocated only then.
+int rocprim_scratch(void** tmp, size_t* have, size_t need)
+{
+    if (*tmp && *have >= need) return SLAM_OK;
+    if (*tmp) hipFree(*tmp);
+    *tmp = nullptr;
+    uint8_t* t = nullptr;
+    int rc = dev_alloc(&t, need ? need : 16);
+    if (rc) return rc;
+    *tmp = t;
+    *have = need;
+    return SLAM_OK;
+}
+
+int sort_by_weight(slam_mcl* h, int64_t n)
+{
+    if (tuning().sort_impl & 1)
+    {
+        if (n <= sortk::SMALL_MAX)
+            sortk::small_sort_pairs(h->keys, h->slots, h->perm, n, h->stream);
+        else if (n <= sortk::MAX_N)
+            sortk::sort_pairs(h->ss_tmp, h->keys, h->slots, h->perm, n, false, h->stream, tuning().ss_lds_cap);
+        else
+            sortk::radix_sort_pairs<double, uint64_t, int32_t>(h->ss_tmp, h->keys, h->slots, h->perm, n, 64, h->stream);
+        HIPCHK(hipGetLastError());
+        return SLAM_OK;
+    }
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs_desc(nullptr, bytes, h->keys, h->keys2, h->slots, h->perm, (size_t)n, 0, 64, h->stream));
+    int rc = rocprim_scratch(&h->sort_tmp, &h->sort_tmp_bytes, bytes);
+    if (rc) return rc;
+    HIPCHK(rocprim::radix_sort_pairs_desc(h->sort_tmp, bytes, h->keys, h->keys2, h->slots, h->perm, (size_t)n, 0, 64, h->stream));
+    return SLAM_OK;
+}
+
+int sort_order_keys(slam_mcl* h, int order_bits)
+{
+    const int64_t n = h->n;
+    if (tuning().sort_impl & 2)
+    {
+        if (n <= sortk::SMALL_MAX)
+            sortk::small_sort_pairs(h->okeys, h->oident, h->order, n, h->stream);
+        else if (n <= sortk::MAX_N)
+            sortk::sort_pairs(h->ss_tmp, h->okeys, h->oident, h->order, n, tuning().order_coarse != 0 && order_bits == 32, h->stream);
+        else
+            sortk::radix_sort_pairs<uint32_t, uint32_t, int32_t>(h->ss_tmp, h->okeys, h->oident, h->order, n, order_bits, h->stream);
+        HIPCHK(hipGetLastError());
+        return SLAM_OK;
+    }
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)n, 0, order_bits, h->stream));
+    int rc = rocprim_scratch(&h->osort_tmp, &h->osort_tmp_bytes, bytes);
+    if (rc) return rc;
+    HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)n, 0, order_bits, h->stream));
+    return SLAM_OK;
+}
 
 // The cloud's bounding boxes (k_order_keys / k_order_box): two on the device, the latest one also in pinned host memory.
 // ... and the buffers of the pose-coherent order (keys, identity, order, rocPRIM scratch).
@@ -277,12 +336,6 @@ int ensure_order_box(slam_mcl* h)
         if ((rc = dev_alloc(&h->okeys, h->n)) || (rc = dev_alloc(&h->okeys2, h->n)) || (rc = dev_alloc(&h->oident, h->n)) ||
             (rc = dev_alloc(&h->order, h->n)))
             return rc;
-        size_t bytes = 0;
-        HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, 32, h->stream));
-        uint8_t* tmp = nullptr;
-        if ((rc = dev_alloc(&tmp, bytes ? bytes : 16))) return rc;
-        h->osort_tmp = tmp;
-        h->osort_tmp_bytes = bytes;
     }
     if (h->obox) return SLAM_OK;
     if ((rc = dev_alloc(&h->obox, 8))) return rc;
@@ -676,13 +729,9 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                 int rc = scan_consumed(h);
                 if (rc) return rc;
             }
-            if (use_sample_sort(h, 2) && order_bits == 32)
-                sortk::sort_pairs(h->ss_tmp, h->okeys, h->oident, h->order, h->n, tuning().order_coarse != 0, h->stream);
-            else
             {
-                size_t bytes = h->osort_tmp_bytes;
-                HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0,
-                                                 order_bits, h->stream));
+                int rc = sort_order_keys(h, order_bits);
+                if (rc) return rc;
             }
             a.order = h->order;
         }
@@ -740,12 +789,9 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
                                tuning().order_sparse, 32, h->okeys, h->oident, h->stats, (const double*)nullptr, h->scan_dev, 0, h->obox,
                                h->order_pass++ & 1, tuning().order_sparse, h->obox_host);
             h->poses_reset = false;
-            if (use_sample_sort(h, 2))
-                sortk::sort_pairs(h->ss_tmp, h->okeys, h->oident, h->order, h->n, tuning().order_coarse != 0, h->stream);
-            else
             {
-                size_t bytes = h->osort_tmp_bytes;
-                HIPCHK(rocprim::radix_sort_pairs(h->osort_tmp, bytes, h->okeys, h->okeys2, h->oident, h->order, (size_t)h->n, 0, 32, h->stream));
+                int rc = sort_order_keys(h, 32);
+                if (rc) return rc;
             }
             a.order = h->order;
         }
@@ -890,14 +936,8 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
     {
         slam_mcl::Span span(h, G_SORT);
         // (weight descending, slot ascending): any stable sort gives this order
-        if (use_sample_sort(h, 1))
-            sortk::sort_pairs(h->ss_tmp, h->keys, h->slots, h->perm, n, false, h->stream, tuning().ss_lds_cap);
-        else
-        {
-            size_t bytes = h->sort_tmp_bytes;
-            HIPCHK(rocprim::radix_sort_pairs_desc(h->sort_tmp, bytes, h->keys, h->keys2, h->slots, h->perm, (size_t)n, 0, 64,
-                                                  h->stream));
-        }
+        int rc = sort_by_weight(h, n);
+        if (rc) return rc;
         perm = h->perm;
     }
     {
@@ -1063,25 +1103,12 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
                 TRY(dev_alloc(&h->lvl_P[l], h->lvl_n[l]));
         }
     }
-    if (!rc && h->prm.sort == SLAM_SORT_FULL)
+    if (!rc && n >= sortk::MIN_N)
     {
-        size_t bytes = 0;
-        hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, bytes, h->keys, h->keys2, h->slots, h->perm, (size_t)n, 0,
-                                                      64, h->stream);
-        if (e != hipSuccess)
-            rc = fail(SLAM_ERR_HIP, std::string("radix sort size query: ") + hipGetErrorString(e));
-        else
-        {
-            h->sort_tmp_bytes = bytes;
-            uint8_t* tmp = nullptr;
-            TRY(dev_alloc(&tmp, bytes ? bytes : 16));
-            h->sort_tmp = tmp;
-        }
-    }
-    if (!rc && n >= sortk::MIN_N && n <= sortk::MAX_N)
-    {
+        // scratch of the library's own sorts, shared by both sorts of a step: the sample sort's, or the radix sort's with
+        // 64-bit keys (the order sort's 32-bit form needs less)
         uint8_t* tmp = nullptr;
-        TRY(dev_alloc(&tmp, sortk::scratch_bytes(n)));
+        TRY(dev_alloc(&tmp, n <= sortk::MAX_N ? sortk::scratch_bytes(n) : sortk::radix_scratch_bytes<uint64_t>(n)));
         h->ss_tmp = tmp;
     }
     if (!rc)

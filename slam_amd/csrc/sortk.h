@@ -28,7 +28,7 @@ namespace sortk
 constexpr int BUCKETS = 1024;
 constexpr int SAMPLES = 4096;  // (2^12: k_ss_sample shifts by 12)
 constexpr int ITEMS = 1024;     // elements per workgroup in steps 2 and 4 (256 threads x 4)
-constexpr int64_t MIN_N = 16384, MAX_N = 262144;
+constexpr int64_t MIN_N = 4097, MAX_N = 262144;  // below: one workgroup ranks everything (small_sort_pairs); above: radix_sort_pairs
 
 struct Scratch
 {
@@ -397,6 +397,197 @@ __host__ inline void sort_pairs(void* scratch, const K* keys, const V* vals, V* 
         hipLaunchKernelGGL((k_ss_scatter<K, V, false>), dim3(nblocks), dim3(256), 0, stream, keys, vals, (int)n, nblocks, s, out_vals);
         hipLaunchKernelGGL((k_ss_buckets<V>), dim3(BUCKETS / GROUP), dim3(256), 0, stream, vals, s, out_vals,
                            lds_cap < GROUP_CAP ? lds_cap : GROUP_CAP);
+    }
+}
+
+// ---- the sizes the sample sort does not serve (round 3: no library sort is left in the filter step) --------------------------
+// n <= SMALL_MAX: ONE workgroup holds every key in LDS and ranks each element by counting the elements below it in the total
+// order (sort key, input position): n^2 / 1024 comparisons per thread, 2 us at 1000 pairs, one launch.
+constexpr int SMALL_MAX = 4096;
+template <typename K, typename V>
+__global__ void __launch_bounds__(1024) k_small_sort(const K* keys, const V* vals, int n, V* out_vals)
+{
+    __shared__ uint64_t sk[SMALL_MAX];
+    const int t = threadIdx.x;
+    for (int e = t; e < n; e += 1024) sk[e] = to_sort_key(keys[e]);
+    __syncthreads();
+    for (int e = t; e < n; e += 1024)
+    {
+        const uint64_t k = sk[e];
+        int r = 0;
+        // entries before e are below it when their key is <= k, entries behind it when their key is < k
+        for (int u = 0; u < e; ++u) r += sk[u] <= k ? 1 : 0;
+        for (int u = e + 1; u < n; ++u) r += sk[u] < k ? 1 : 0;
+        out_vals[r] = vals[e];
+    }
+}
+template <typename K, typename V>
+__host__ inline void small_sort_pairs(const K* keys, const V* vals, V* out_vals, int64_t n, hipStream_t stream)
+{
+    hipLaunchKernelGGL((k_small_sort<K, V>), dim3(1), dim3(1024), 0, stream, keys, vals, (int)n, out_vals);
+}
+
+// n > MAX_N: least-significant-digit radix sort, 8 bits per pass, three launches per pass: digit counts per workgroup of
+// RX_ITEMS elements; one workgroup per digit turns its row of counts into exclusive offsets; every element goes to
+// (first position of its digit) + (elements of that digit in earlier workgroups) + (its rank among this workgroup's elements
+// of that digit, in input order): stable, so after the last pass the order is (sort key, input position), the same total
+// order as the sample sort's and as any stable sort's.  Keys travel as sort keys (uint32 order keys as they are, weights
+// through to_sort_key once, in the first pass); the values ping-pong between one scratch array and out_vals.
+constexpr int RX_ITEMS = 2048;
+template <typename SK>
+__device__ __forceinline__ SK rx_key(const uint32_t* keys, int64_t i) { return (SK)keys[i]; }
+template <typename SK>
+__device__ __forceinline__ SK rx_key(const uint64_t* keys, int64_t i) { return (SK)keys[i]; }
+template <typename SK>
+__device__ __forceinline__ SK rx_key(const double* keys, int64_t i) { return (SK)to_sort_key(keys[i]); }
+
+template <typename K, typename SK>
+__global__ void __launch_bounds__(256) k_rx_hist(const K* keys, int64_t n, int shift, int nblocks, int32_t* counts)
+{
+    __shared__ int hist[256];
+    const int t = threadIdx.x;
+    hist[t] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS / 256; ++j)
+    {
+        const int64_t i = (int64_t)blockIdx.x * RX_ITEMS + j * 256 + t;
+        if (i < n) atomicAdd(&hist[(int)((rx_key<SK>(keys, i) >> shift) & 255)], 1);
+    }
+    __syncthreads();
+    counts[(size_t)t * nblocks + blockIdx.x] = hist[t];
+}
+
+// row d of counts (digit d, one entry per workgroup) becomes its exclusive scan; dtot[d] = the row's sum
+__global__ void __launch_bounds__(256) k_rx_scan(int nblocks, int32_t* counts, int32_t* dtot)
+{
+    __shared__ int part[256];
+    const int t = threadIdx.x;
+    int32_t* row = counts + (size_t)blockIdx.x * nblocks;
+    int carry = 0;
+    for (int base = 0; base < nblocks; base += 256)
+    {
+        const int c = base + t < nblocks ? row[base + t] : 0;
+        part[t] = c;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1)
+        {
+            const int v = t >= d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        if (base + t < nblocks) row[base + t] = carry + part[t] - c;
+        carry += part[255];
+        __syncthreads();
+    }
+    if (t == 0) dtot[blockIdx.x] = carry;
+}
+
+template <typename K, typename SK, typename V>
+__global__ void __launch_bounds__(256) k_rx_scatter(const K* keys, const V* vals, int64_t n, int shift, int nblocks, const int32_t* counts,
+                                                    const int32_t* dtot, SK* keys_out /* nullptr: the last pass */, V* vals_out)
+{
+    __shared__ int run[256];
+    __shared__ int tmp[256];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // first position of digit t = sum of the totals of the digits below it
+    const int mine = dtot[t];
+    tmp[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1)
+    {
+        const int v = t >= d ? tmp[t - d] : 0;
+        __syncthreads();
+        tmp[t] += v;
+        __syncthreads();
+    }
+    run[t] = tmp[t] - mine + counts[(size_t)t * nblocks + blockIdx.x];
+    __syncthreads();
+    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll 1
+    for (int j = 0; j < RX_ITEMS / 256; ++j)
+    {
+        const int64_t i = (int64_t)blockIdx.x * RX_ITEMS + j * 256 + t;
+        const bool valid = i < n;
+        const SK k = valid ? rx_key<SK>(keys, i) : (SK)0;
+        const int b = (int)((k >> shift) & 255);
+        uint64_t same = __ballot(valid);  // lanes of this wavefront with the same digit
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit)
+        {
+            const uint64_t bal = __ballot((b >> bit) & 1);
+            same &= ((b >> bit) & 1) ? bal : ~bal;
+        }
+        const int before = __popcll(same & lt), cnt = __popcll(same);
+        int base = 0;
+        for (int w = 0; w < 4; ++w)
+        {  // the wavefronts of the workgroup in turn: input order
+            if (wave == w && valid && before == 0)
+            {
+                base = run[b];
+                run[b] = base + cnt;
+            }
+            __syncthreads();
+        }
+        base = __shfl(base, valid ? (int)__builtin_ctzll(same) : lane);
+        if (valid)
+        {
+            const int64_t dst = (int64_t)base + before;
+            if (keys_out) keys_out[dst] = k;
+            vals_out[dst] = vals[i];
+        }
+    }
+}
+
+template <typename SK>
+__host__ inline size_t radix_scratch_bytes(int64_t n)
+{
+    const size_t nb = (size_t)((n + RX_ITEMS - 1) / RX_ITEMS);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return 2 * up(sizeof(SK) * (size_t)n) + up(4 * (size_t)n) + up(4 * 256 * nb) + up(4 * 256);
+}
+
+// key_bits: significant low bits of the sort key (32-bit order keys: what the caller packed; weights: 64).  n < 2^31.
+template <typename K, typename SK, typename V>
+__host__ inline void radix_sort_pairs(void* scratch, const K* keys, const V* vals, V* out_vals, int64_t n, int key_bits, hipStream_t stream)
+{
+    const int nblocks = (int)((n + RX_ITEMS - 1) / RX_ITEMS);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    uint8_t* p = static_cast<uint8_t*>(scratch);
+    SK* kbuf[2];
+    kbuf[0] = reinterpret_cast<SK*>(p);
+    p += up(sizeof(SK) * (size_t)n);
+    kbuf[1] = reinterpret_cast<SK*>(p);
+    p += up(sizeof(SK) * (size_t)n);
+    V* vbuf = reinterpret_cast<V*>(p);
+    p += up(4 * (size_t)n);
+    int32_t* counts = reinterpret_cast<int32_t*>(p);
+    p += up(4 * 256 * (size_t)nblocks);
+    int32_t* dtot = reinterpret_cast<int32_t*>(p);
+    int passes = (key_bits + 7) / 8;
+    if (passes < 1) passes = 1;
+    if (passes & 1) ++passes;  // an even number of passes: the values end in out_vals (a pass over zero digits is the identity)
+    for (int ps = 0; ps < passes; ++ps)
+    {
+        const int shift = 8 * ps;
+        const bool last = ps == passes - 1;
+        const V* vin = ps == 0 ? vals : ((ps & 1) ? vbuf : out_vals);
+        V* vout = (ps & 1) ? out_vals : vbuf;
+        SK* kout = last ? nullptr : kbuf[ps & 1];
+        if (ps == 0)
+        {
+            hipLaunchKernelGGL((k_rx_hist<K, SK>), dim3(nblocks), dim3(256), 0, stream, keys, n, shift, nblocks, counts);
+            hipLaunchKernelGGL(k_rx_scan, dim3(256), dim3(256), 0, stream, nblocks, counts, dtot);
+            hipLaunchKernelGGL((k_rx_scatter<K, SK, V>), dim3(nblocks), dim3(256), 0, stream, keys, vin, n, shift, nblocks, counts, dtot, kout, vout);
+        }
+        else
+        {
+            const SK* kin = kbuf[(ps - 1) & 1];
+            hipLaunchKernelGGL((k_rx_hist<SK, SK>), dim3(nblocks), dim3(256), 0, stream, kin, n, shift, nblocks, counts);
+            hipLaunchKernelGGL(k_rx_scan, dim3(256), dim3(256), 0, stream, nblocks, counts, dtot);
+            hipLaunchKernelGGL((k_rx_scatter<SK, SK, V>), dim3(nblocks), dim3(256), 0, stream, kin, vin, n, shift, nblocks, counts, dtot, kout, vout);
+        }
     }
 }
 }  // namespace sortk

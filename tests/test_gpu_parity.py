@@ -514,9 +514,10 @@ def test_resample_indices_bit_exact_beyond_the_sample_sort(sa, order, N):
     assert distinct > N // 4
 
 
-@pytest.mark.parametrize("N", [16384, 50001, 100000, 262144])
+@pytest.mark.parametrize("N", [1000, 4096, 4097, 16384, 50001, 100000, 262144, 262145, 600000])
 def test_weight_sort_of_the_sample_sort_sizes(sa, N):
-    """slam/mcl.cpp:232-239 at the sizes served by the sample sort of sortk.h (16k..256k particles): the order must be
+    """slam/mcl.cpp:232-239 on the library's own sorts (sortk.h): one workgroup up to 4096 particles, the sample sort up to
+    262 144, the radix sort beyond (no library sort is left in the step).  The order must be
     (weight descending, slot ascending) whatever the weights look like: heavy ties (few distinct weights, so that most
     buckets' splitters are decided by the slot), one surviving particle (every key equal), already sorted and reversed
     inputs, a tiny dynamic range, and one value that owns half of the array (its bucket does not fit LDS if the
@@ -560,7 +561,7 @@ import sys, numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
 import _oracle as orc, slam_amd as sa
 out = {}
-for N in (20000, 100000):
+for N in (1000, 5000, 20000, 100000, 300000):
     rng = np.random.default_rng(N)
     f = sa.Filter(N, 16, 16, noise=sa.capi.NOISE_INJECTED)
     for name, w in (("generic", rng.uniform(0, 1, N) ** 8), ("ties", rng.choice([1e-300, 0.25, 0.5], N))):
