@@ -283,6 +283,11 @@ int slam_mcl_device_maps_get(slam_mcl* h, slam_mcl_device_maps* out);
  * excluded), tiles handed out since}.  A pool that runs dry makes the call that notices it return
  * SLAM_ERR_NOMEM (canvases are then incomplete: recreate the handle with a larger pool). */
 int slam_mcl_get_tile_stats(slam_mcl* h, int64_t out[3]);
+/* SLAM_MAPS_TILED: {slam_mcl_update calls so far, how many of them left their canvases for the resample that follows
+ * ("weights now, canvases of the survivors later": DESIGN.md), particles of the last such update that took the ordinary
+ * pass at once because their sensor was too close to row 0 / column 0}.  Results do not depend on which way an update
+ * went; the numbers are for tests and benchmarks.  No counterpart in the reference (slam/mcl.cpp:102-144 always draws). */
+int slam_mcl_get_defer_stats(slam_mcl* h, int64_t out[3]);
 int slam_mcl_synchronize(slam_mcl* h);
 
 /* FakeLidar::scan (slam/fake_lidar.cpp:15-33) + raycast<int> (slam/raycast.cpp:100-141), batched

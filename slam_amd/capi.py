@@ -101,6 +101,7 @@ SYMBOLS = {
     "slam_mcl_shift_tables": (ctypes.c_int, [_P, _P, _I64, _I32]),
     "slam_mcl_device_maps_get": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_tile_stats": (ctypes.c_int, [_P, _P]),
+    "slam_mcl_get_defer_stats": (ctypes.c_int, [_P, _P]),
     "slam_mcl_get_poses": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64]),
     "slam_mcl_get_weights": (ctypes.c_int, [_P, _P, _I64, _I64]),
     "slam_mcl_get_map_u8": (ctypes.c_int, [_P, _I64, _P]),

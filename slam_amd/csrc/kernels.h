@@ -146,7 +146,21 @@ struct WeightArgs
     const int32_t* order;       // optional: slot -> particle (pose-coherent order, see k_order_keys)
     int log_domain;             // SLAM_WEIGHT_LOG: store the sum of logs instead of its exp
     int clamp_limit;            // localization hit search: stop a ray once it is beyond z + 4 sigma (ray_fast_L0's k_lim); off when hits are recorded
+    double defer_edge;          // deferred canvases: how far the sensor must be from the two-wide cells of row 0 / column 0 (slam_defer_safe)
 };
+
+// "Weights now, canvases later" (TiledDefer) rests on two rays of a scan sharing no cell beyond kstar samples, which holds
+// for cells one unit wide.  The casts of slam/raycast.cpp:171 truncate toward zero, so x in (-1, 1) is column 0 and
+// rows - y - 1 in (-1, 1) is row 0: those cells are two units wide and two rays can meet in one of them twice as far out.
+// A particle whose sensor is at least edge = 2 sqrt(2) / sin(gap) + 2 away from both bands (-1, 0) has no ray that comes
+// within 2 sqrt(2) of a point another ray has in such a band; the others take the ordinary pass right away.
+__device__ __forceinline__ bool slam_defer_safe(double sx, double sy, double rows_d, double edge)
+{
+    const double u = sx, v = (rows_d - sy) - 1.0;
+    const double du = u >= 0.0 ? u : (u <= -1.0 ? -1.0 - u : 0.0);
+    const double dv = v >= 0.0 ? v : (v <= -1.0 ? -1.0 - v : 0.0);
+    return du >= edge && dv >= edge;  // (false for a NaN pose)
+}
 
 // K2a.  VARIANT 0: ray_fast_L on the clearance grid.  VARIANT 1: literal walk on the raw map
 // (counts cells).  One wavefront = one particle; lane l takes beams l, l+64, ...; the per-beam
@@ -1309,10 +1323,14 @@ struct TilePlanCtx
 // One wavefront per TILE_PLAN_PW particles, 16 wavefronts per block; the tiles are evaluated twice (count, then
 // list) so that a whole block takes ONE range of the free list: the allocation cursor is a single
 // address, and one atomic per particle on it cost more than everything else in this kernel.
+// sub_list / sub_count: plan for the particles sub_list[0 .. *sub_count) only (the survivors of a resample whose weighting
+// pass left the canvases untouched, see TiledDefer in slam_s2.h); nullptr: all n particles.
 __global__ void __launch_bounds__(1024) k_tile_plan(int64_t n, const double* x, const double* y, const double* th, double sd,
                                                     double stheta, double srot, double range, const float* sector_r, int rows,
-                                                    int cols, int side, TileArgs ta, TilePlan pl)
+                                                    int cols, int side, TileArgs ta, TilePlan pl, const int32_t* sub_list,
+                                                    const int* sub_count)
 {
+    if (sub_list) n = *sub_count;
     __shared__ int cnt_s, base_s;
     __shared__ uint64_t votes_s[16][TILE_PLAN_PW][16];  // the votes of the counting pass (side <= 31: at most 16 x 64 tiles)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1326,8 +1344,8 @@ __global__ void __launch_bounds__(1024) k_tile_plan(int64_t n, const double* x, 
         int running = 0;
         for (int k = 0; k < TILE_PLAN_PW; ++k)
         {
-            const int64_t p = p_first + k;
-            if (p >= n) break;  // whole wavefront
+            if (p_first + k >= n) break;  // whole wavefront
+            const int64_t p = sub_list ? (int64_t)sub_list[p_first + k] : p_first + k;
             double s, c;
             dm_sincos(th[p] + stheta, &s, &c);
             TilePlanCtx cx;
@@ -1391,6 +1409,53 @@ __global__ void __launch_bounds__(1024) k_tile_plan(int64_t n, const double* x, 
             __syncthreads();
         }
     }
+}
+
+// The distinct sources of a selection (slam/mcl.cpp:179-203 picks with replacement): every selected particle is stamped
+// with this resample's number, then the stamped particles are listed, one counter atomic per wavefront.  The order of
+// the list is whatever the atomics make it: it only decides which free tile a survivor's copy lands in.
+__global__ void __launch_bounds__(256) k_mark_sources(const int32_t* idx, int64_t n_slots, int64_t first_local, int64_t n_local, int gen,
+                                                      int* stamp)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_slots) return;
+    const int64_t s = (int64_t)idx[k] - first_local;
+    if (s >= 0 && s < n_local) stamp[s] = gen;
+}
+// (skip: particles whose canvases are up to date already, see k_defer_split)
+__global__ void __launch_bounds__(256) k_list_sources(const int* stamp, int64_t n_local, int gen, int32_t* list, int* count, const uint8_t* skip)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool is = p < n_local && stamp[p] == gen && !(skip && skip[p]);
+    const uint64_t vote = __ballot(is);
+    if (!vote) return;
+    int base = 0;
+    const int leader = __ffsll((long long)vote) - 1;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(count, __popcll(vote));
+    base = __shfl(base, leader);
+    if (is) list[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0))] = (int32_t)p;
+}
+
+// The particles of a deferred pass that cannot defer (slam_defer_safe): flagged, and listed for the ordinary pass that
+// follows at once.
+__global__ void __launch_bounds__(256) k_defer_split(WeightArgs a, uint8_t* flag, int32_t* list, int* count)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool is = false;
+    if (p < a.n)
+    {
+        double s0, c0;
+        dm_sincos(a.th[p] + a.stheta, &s0, &c0);
+        is = !slam_defer_safe(a.x[p] + c0 * a.sd, a.y[p] + s0 * a.sd, (double)a.rows, a.defer_edge);
+        flag[p] = is ? 1 : 0;
+    }
+    const uint64_t vote = __ballot(is);
+    if (!vote) return;
+    int base = 0;
+    const int leader = __ffsll((long long)vote) - 1;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(count, __popcll(vote));
+    base = __shfl(base, leader);
+    if (is) list[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0))] = (int32_t)p;
 }
 
 // first = allocation cursor before k_tile_plan (ctrl[3]); block b takes free-list positions first + b,

@@ -147,6 +147,21 @@ struct slam_mcl
     unsigned long long* stats = nullptr;
     double* partials = nullptr;
     bool sparse_last = false;  // the kernel shape the last pass chose from the cloud's box (hysteresis)
+    // deferred canvases (TiledDefer): the weighting pass of slam_mcl_update left the canvases untouched; the resample brings
+    // the selected particles' canvases up to date before it hands their tables on
+    bool deferred = false;
+    int rp_B = 0;
+    double rp_stddev = 0, rp_max_dist = 0, rp_off[3] = {0, 0, 0};
+    int* surv_stamp = nullptr;      // per particle: number of the last resample that selected it
+    int32_t* surv_list = nullptr;   // the distinct selected particles of the current resample
+    int* surv_count = nullptr;      // device: how many
+    int* surv_count_host = nullptr; // pinned: the count of an earlier resample (read late, decides the mode only)
+    int surv_gen = 0;
+    uint8_t* edge_flag = nullptr;   // deferred pass: 1 = this particle took the ordinary pass at once (slam_defer_safe)
+    int32_t* edge_list = nullptr;   // those particles
+    int* edge_count = nullptr;
+    bool edge_valid = false;        // edge_flag belongs to the pending deferred pass
+    int64_t n_updates = 0, n_deferred = 0;  // slam_mcl_get_defer_stats
     double* lw = nullptr;  // scratch of the particle-lane weight kernels
     size_t lw_cap = 0;     // doubles
     uint32_t *okeys = nullptr, *okeys2 = nullptr;  // pose-coherent order of the particle-lane kernels
@@ -250,6 +265,9 @@ struct Tuning
     int order_sparse;// SLAM_PL_ORDER_SPARSE: order mode of the wave-per-particle kernel on a sparse cloud (0 = index order)
     int beam_cells;  // SLAM_BEAM_CELLS: cells of the cloud's bounding box per particle above which the wave-per-particle kernel runs (0 = never)
     int tile_fuse;   // SLAM_TILE_FUSE: 1 = the two-phase kernel makes the planned tile copies itself (default), 0 = k_tile_copy before it
+    int defer;       // SLAM_DEFER: grid-SLAM update on tiles, "weights now, canvases of the survivors later" (TiledDefer, slam_s2.h):
+                     // 0 = never, 1 = when the last resample kept fewer than half of the particles (default), 2 = whenever the scan allows
+    int defer_fast;  // SLAM_DEFER_FAST: 1 = the weights-only kernel k_weights_S2F for the first half (default), 0 = k_weights_S2<DEFER>
 };
 const Tuning& tuning()
 {
@@ -259,7 +277,7 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 4 | (7 << 4) | (8 << 8)), env_int("SLAM_PL_ORDER_SPARSE", 4 | (7 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 4 | (7 << 4) | (8 << 8)), env_int("SLAM_PL_ORDER_SPARSE", 4 | (7 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1), env_int("SLAM_DEFER", 1), env_int("SLAM_DEFER_FAST", 1)};
     return t;
 }
 
@@ -478,7 +496,10 @@ int flush_scan(slam_mcl* h)
     return scan_consumed(h);
 }
 
-int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double off[3])
+// pass_mode 0: the pass as the reference runs it (canvases updated).  1 (slam_mcl_update, which resamples right away): may
+// leave the canvases untouched and set h->deferred (TiledDefer).  2: the second half of that, called by do_resample: the
+// ordinary pass on the particles of h->surv_list only, nothing recorded.
+int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double off[3], int pass_mode = 0)
 {
     if (!(stddev > 0) || !std::isfinite(stddev) || !(max_dist >= 0) || !std::isfinite(max_dist))
         return fail(SLAM_ERR_ARG, "stddev must be > 0 and max_dist >= 0, both finite");
@@ -487,7 +508,8 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     const bool slam_mode = h->prm.mode == SLAM_MODE_SLAM;
     if (!slam_mode && !h->have_map) return fail(SLAM_ERR_STATE, "localization mode: call slam_mcl_set_map_u8 first");
     if (h->maps_pending) return fail(SLAM_ERR_STATE, "canvases of the last slam_mcl_shard_select are still pending (slam_mcl_shard_clone_maps)");
-    if (h->record_hits)
+    const bool replay = pass_mode == 2;
+    if (h->record_hits && !replay)
     {
         const size_t need = (size_t)h->n * B;
         if (need > h->hit_cap)
@@ -525,6 +547,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.nseg = a.seg_beams = 0;
     a.order = nullptr;
     a.log_domain = h->prm.weight_domain == SLAM_WEIGHT_LOG;
+    a.defer_edge = 0.0;
     // slam/mcl.cpp:80-86 with the int-returning squared distance of slam/util.h:138-146
     {
         const double ddx = 0 - off[0], ddy = 0 - off[1];
@@ -538,8 +561,8 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     a.k_safe = ks < 0 ? 0 : ks;
     a.max_iter = (int)std::ceil(std::fmin(a.zmax, 1.0e6)) + 8;
     a.w = h->w;
-    a.hit_xy = h->record_hits ? h->hit_xy : nullptr;
-    a.hit_cell = h->record_hits ? h->hit_cell : nullptr;
+    a.hit_xy = h->record_hits && !replay ? h->hit_xy : nullptr;
+    a.hit_cell = h->record_hits && !replay ? h->hit_cell : nullptr;
     a.clamp_limit = !h->record_hits && tuning().clamp_limit;  // recorded hits are the reference's, wherever they lie
     a.stats = h->stats;
     a.luts = h->luts;
@@ -567,7 +590,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     const bool particle_lanes = !slam_mode && (h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES ||
                                                h->prm.raycaster == SLAM_RAYCAST_FAST_PARTICLE_LANES_DIRECT ||
                                                (h->prm.raycaster == SLAM_RAYCAST_FAST && h->n >= 4096 && !sparse_cloud));
-    if (!(particle_lanes && order_mode > 0 && h->n >= 3))  // k_order_keys zeroes the counters itself
+    if (!(particle_lanes && order_mode > 0 && h->n >= 3) && !replay)  // k_order_keys zeroes the counters itself
         HIPCHK(hipMemsetAsync(h->stats, 0, 3 * sizeof(unsigned long long), h->stream));
     if (!(particle_lanes && order_mode > 0 && tuning().scan_fuse))  // k_order_keys also brings the new scan to scan_dev
     {
@@ -588,6 +611,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
     }
     std::unique_ptr<slam_mcl::Span> wspan;
     if (!(slam_mode && h->tiled)) wspan.reset(new slam_mcl::Span(h, G_WEIGHTS));
+    const bool stats_on = h->collect_stats && !replay;
     h->ext_timing = false;
     if (slam_mode)
     {
@@ -608,9 +632,68 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         const int s2_literal = (tuning().s_kernel == 2 || h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE_LITERAL) ? 1 : 0;
         if ((h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE || h->prm.raycaster == SLAM_RAYCAST_TWO_PHASE_LITERAL) && !two_phase)
             return fail(SLAM_ERR_ARG, "SLAM_RAYCAST_TWO_PHASE: max_dist too large for the LDS of one wavefront");
+        // "weights now, canvases later": possible when the pass's own writes that a later ray can meet fit an LDS window
+        int dk = 0, dw = 0;
+        bool defer = false;
+        if (pass_mode == 1 && h->tiled && two_phase && tuning().tile_fuse != 0 && tuning().defer != 0 && h->prm.raycaster == SLAM_RAYCAST_FAST &&
+            h->surv_list)
+        {
+            // smallest angular gap between two beams of the scan (directions, modulo a turn)
+            std::vector<double> ang(h->scan_cache.begin(), h->scan_cache.begin() + B);
+            for (double& v : ang)
+            {
+                v = std::fmod(v, 2 * M_PI);
+                if (v < 0) v += 2 * M_PI;
+            }
+            std::sort(ang.begin(), ang.end());
+            double gap = B > 1 ? ang[0] + 2 * M_PI - ang[B - 1] : M_PI;
+            for (int b = 1; b < B; ++b) gap = std::fmin(gap, ang[b] - ang[b - 1]);
+            // two rays from one origin, `gap` apart, pass farther than sqrt(2) from each other beyond sqrt(2) / sin(gap)
+            // cells from it: no common cell there; one cell of margin for the accumulated positions, one for the sample count
+            const double rstar = gap >= M_PI / 2 ? 1.4143 : (gap > 1.0e-6 ? 1.4143 / std::sin(gap) : 1.0e9);
+            a.defer_edge = 2.0 * rstar + 2.0;
+            if (rstar < 60.0)
+            {
+                dk = (int)std::ceil(rstar + 1.0) + 1;
+                dw = ((2 * (dk + 2) + 1 + 14) + 7) & ~7;
+                const bool few_survive = h->surv_count_host && *(volatile int*)h->surv_count_host >= 0 &&
+                                         2 * (int64_t)(*(volatile int*)h->surv_count_host) < h->n;
+                // (below 8192 particles the step is one chain of dependent rays long: a second pass over the survivors costs
+                //  more than the copies it saves; SLAM_DEFER=2 defers regardless, for the tests)
+                defer = s2_lds + (size_t)dw * dw <= 60 * 1024 && (tuning().defer == 2 || (few_survive && h->n >= 8192));
+            }
+        }
+        if (h->tiled && defer)
+        {
+            // the canvases stay as they are; do_resample runs the ordinary pass on the particles it selects.  (Particles too
+            // close to row 0 / column 0 for that, slam_defer_safe, are listed and take the ordinary pass below.)
+            h->deferred = true;
+            h->edge_valid = true;
+            ++h->n_deferred;
+            HIPCHK(hipMemsetAsync(h->edge_count, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(slamk::k_defer_split, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, a, h->edge_flag, h->edge_list, h->edge_count);
+            h->rp_B = B;
+            h->rp_stddev = stddev;
+            h->rp_max_dist = max_dist;
+            for (int k = 0; k < 3; ++k) h->rp_off[k] = off[k];
+            wspan.reset(new slam_mcl::Span(h, G_WEIGHTS));
+            const slamk::S2Subset all = {nullptr, nullptr};
+            const size_t lds = s2_lds + (size_t)dw * dw;
+            if (stats_on)
+                hipLaunchKernelGGL((slamk::k_weights_S2<true, true, true>), dim3((unsigned)h->n), dim3(64), lds, h->stream, a, ta, npass, win_w,
+                                   s2_literal, all, dk, dw);
+            else if (tuning().defer_fast)
+                hipLaunchKernelGGL(slamk::k_weights_S2F, dim3((unsigned)h->n), dim3(64), (size_t)512 + 1024 + (size_t)win_w * win_w * 4 + (size_t)dw * dw,
+                                   h->stream, a, ta, win_w, s2_literal, dk, dw);
+            else
+                hipLaunchKernelGGL((slamk::k_weights_S2<true, false, true>), dim3((unsigned)h->n), dim3(64), lds, h->stream, a, ta, npass, win_w,
+                                   s2_literal, all, dk, dw);
+            wspan.reset();
+        }
         if (h->tiled)
         {
             // make every tile within sensor range exclusive up front (parallel), then walk
+            const slamk::S2Subset sub = {defer ? h->edge_list : (replay ? h->surv_list : nullptr), defer ? h->edge_count : (replay ? h->surv_count : nullptr)};
             std::unique_ptr<slam_mcl::Span> copies(new slam_mcl::Span(h, G_CLONE));
             // (no farther than the scan's farthest write: min(z, zmax) + 2 over its beams, plus a cell of margin)
             double range = 0.0;
@@ -647,7 +730,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             }
             if (!fuse) hipLaunchKernelGGL(slamk::k_tile_mark, dim3(1), dim3(1), 0, h->stream, h->tile_ctrl);  // (where k_tile_copy starts)
             hipLaunchKernelGGL(slamk::k_tile_plan, dim3((unsigned)cdiv(h->n, 16 * slamk::TILE_PLAN_PW)), dim3(1024), 0, h->stream, h->n, h->x, h->y, h->th, a.sd,
-                               a.stheta, a.srot, range, h->tile_sector, h->rows, h->cols, side, ta, pl);
+                               a.stheta, a.srot, range, h->tile_sector, h->rows, h->cols, side, ta, pl, sub.list, sub.count);
             if (fuse)
             {
                 ta.plan_rng = h->tile_rng;
@@ -656,28 +739,28 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             else
                 hipLaunchKernelGGL(slamk::k_tile_copy, dim3((unsigned)blocks), dim3(256), 0, h->stream, ta, pl);
             copies.reset();
-            wspan.reset(new slam_mcl::Span(h, G_WEIGHTS));
+            wspan.reset(new slam_mcl::Span(h, replay ? G_CLONE : G_WEIGHTS));  // (the second half of a deferred pass IS the deferred deep copy)
             size_t lds = 0;
             if ((size_t)h->tile_T * 16 <= 48 * 1024)
             {
                 ta.lds_entries = h->tile_T;
                 lds = (size_t)h->tile_T * 16;
             }
-            if (two_phase && h->collect_stats)
+            if (two_phase && stats_on)
                 hipLaunchKernelGGL((slamk::k_weights_S2<true, true>), dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
-                                   s2_literal);
+                                   s2_literal, sub, 0, 0);
             else if (two_phase)
                 hipLaunchKernelGGL((slamk::k_weights_S2<true, false>), dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
-                                   s2_literal);
+                                   s2_literal, sub, 0, 0);
             else
                 hipLaunchKernelGGL(slamk::k_weights_S_wave<true>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), lds, h->stream, a, ta);
         }
-        else if (two_phase && h->collect_stats)
+        else if (two_phase && stats_on)
             hipLaunchKernelGGL((slamk::k_weights_S2<false, true>), dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
-                               s2_literal);
+                               s2_literal, slamk::S2Subset{nullptr, nullptr}, 0, 0);
         else if (two_phase)
             hipLaunchKernelGGL((slamk::k_weights_S2<false, false>), dim3((unsigned)h->n), dim3(64), s2_lds, h->stream, a, ta, npass, win_w,
-                               s2_literal);
+                               s2_literal, slamk::S2Subset{nullptr, nullptr}, 0, 0);
         else if (wave)
             hipLaunchKernelGGL(slamk::k_weights_S_wave<false>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a, ta);
         else
@@ -931,6 +1014,29 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
         hipLaunchKernelGGL(slamk::k_select, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, s);
         HIPCHK(hipGetLastError());
     }
+    if (h->surv_list && n_shards == 1 && clone_local)
+    {
+        // the distinct particles this resample selected: how many (read by a later update, which then decides whether to
+        // defer its canvases) and, after a deferred weighting pass, which: their canvases are brought up to date now, by
+        // the ordinary pass on them alone, before their tables are handed to their children below (slam/mcl.cpp:147-155
+        // copies the maps the update has just drawn)
+        slam_mcl::Span span(h, G_CLONE);
+        const int gen = ++h->surv_gen;
+        HIPCHK(hipMemsetAsync(h->surv_count, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(slamk::k_mark_sources, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, h->idx, n, (int64_t)0, n, gen, h->surv_stamp);
+        hipLaunchKernelGGL(slamk::k_list_sources, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, h->surv_stamp, n, gen, h->surv_list, h->surv_count,
+                           h->deferred && h->edge_valid ? h->edge_flag : nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->surv_count_host, h->surv_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (h->deferred)
+    {
+        h->deferred = false;
+        h->edge_valid = false;
+        if (!(h->surv_list && n_shards == 1 && clone_local)) return fail(SLAM_ERR_STATE, "resample: deferred canvases without a local resample (library bug)");
+        int rc = do_weights(h, h->rp_B, h->rp_stddev, h->rp_max_dist, h->rp_off, 2);
+        if (rc) return rc;
+    }
     const int32_t* perm = nullptr;
     if (h->prm.sort == SLAM_SORT_FULL)
     {
@@ -991,7 +1097,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
     void* ptrs[] = {h->state, h->state2,
                     h->grid,  h->clr,    h->maps, h->maps2,    h->luts,         h->scan_dev,
                     h->inj_normals, h->inj_uniforms, h->idx, h->perm, h->slots, h->src,   h->keys, h->keys2,
-                    h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw,
+                    h->sort_tmp, h->hit_xy, h->hit_cell, h->stats, h->partials, h->lw, h->surv_stamp, h->surv_list, h->surv_count, h->edge_flag, h->edge_list, h->edge_count,
                     h->okeys, h->okeys2, h->obox, h->oident, h->order, h->osort_tmp, h->ss_tmp, h->wlin, h->wmax,
                     h->tile_pool, h->tile_tab, h->tile_tab2, h->tile_free, h->tile_ref, h->tile_who, h->tile_shared, h->tile_ctrl, h->tile_dense, h->tile_sector,
                     h->tile_wl_p, h->tile_wl_t, h->tile_rng, h->pack_stamp, h->pack_ctr, h->pack_slot, h->dev_bad};
@@ -1000,6 +1106,7 @@ SLAM_API void slam_mcl_destroy(slam_mcl* h)
     for (int k = 0; k < slam_mcl::SCAN_RING; ++k)
         if (h->scan_pin[k]) hipHostFree(h->scan_pin[k]);
     if (h->obox_host) hipHostFree(h->obox_host);
+    if (h->surv_count_host) hipHostFree(h->surv_count_host);
     for (int g = 0; g < slam_mcl::SCAN_RING / slam_mcl::SCAN_GROUP; ++g)
         if (h->scan_ev[g]) hipEventDestroy(h->scan_ev[g]);
     for (size_t l = 0; l < h->lvl_s.size(); ++l)
@@ -1143,6 +1250,19 @@ SLAM_API int slam_mcl_create(const slam_mcl_params* params, slam_mcl** out)
         TRY(dev_alloc(&h->tile_wl_p, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_wl_t, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_rng, 2 * (size_t)n));
+        if (h->n_glob == n)
+        {  // (one handle holds the whole filter: the resample is local, canvases may be deferred)
+            TRY(dev_alloc(&h->surv_stamp, (size_t)n));
+            TRY(dev_alloc(&h->surv_list, (size_t)n));
+            TRY(dev_alloc(&h->surv_count, 1));
+            TRY(dev_alloc(&h->edge_flag, (size_t)n));
+            TRY(dev_alloc(&h->edge_list, (size_t)n));
+            TRY(dev_alloc(&h->edge_count, 1));
+            if (!rc && hipMemset(h->surv_stamp, 0, sizeof(int) * (size_t)n) != hipSuccess) rc = fail(SLAM_ERR_HIP, "hipMemset");
+            if (!rc && hipHostMalloc(reinterpret_cast<void**>(&h->surv_count_host), sizeof(int), hipHostMallocDefault) != hipSuccess)
+                rc = fail(SLAM_ERR_HIP, "hipHostMalloc");
+            if (!rc) *h->surv_count_host = -1;  // no resample yet: the first update runs the ordinary pass
+        }
         TRY(dev_alloc(&h->tile_ref, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_who, (size_t)h->tile_cap));
         TRY(dev_alloc(&h->tile_shared, (size_t)h->tile_cap));
@@ -1676,6 +1796,25 @@ SLAM_API int slam_mcl_get_tile_stats(slam_mcl* h, int64_t out[3])
     return SLAM_OK;
 }
 
+SLAM_API int slam_mcl_get_defer_stats(slam_mcl* h, int64_t out[3])
+{
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out) return fail(SLAM_ERR_ARG, "null");
+    if (!h->tiled) return fail(SLAM_ERR_STATE, "get_defer_stats: the handle holds dense canvases");
+    out[0] = h->n_updates;
+    out[1] = h->n_deferred;
+    out[2] = 0;
+    if (h->n_deferred && h->edge_count)
+    {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        int c = 0;
+        HIPCHK(hipMemcpy(&c, h->edge_count, sizeof(int), hipMemcpyDeviceToHost));
+        out[2] = c;
+    }
+    return SLAM_OK;
+}
+
 SLAM_API int slam_mcl_device_maps_get(slam_mcl* h, slam_mcl_device_maps* out)
 {
     if (!h || !out) return fail(SLAM_ERR_ARG, "null");
@@ -1692,7 +1831,8 @@ SLAM_API int slam_mcl_update(slam_mcl* h, const double* angles, const double* di
     int rc = check_handle(h);
     if (rc) return rc;
     if ((rc = upload_scan(h, angles, dists, n_beams))) return rc;
-    if ((rc = do_weights(h, n_beams, stddev, max_dist, scanner_offset))) return rc;
+    ++h->n_updates;
+    if ((rc = do_weights(h, n_beams, stddev, max_dist, scanner_offset, 1))) return rc;  // (resampled right away: canvases may wait)
     if ((rc = do_resample(h, nullptr, 1))) return rc;
     return maybe_finish(h);
 }

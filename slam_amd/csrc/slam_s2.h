@@ -36,6 +36,7 @@ enum { S2_NP = 1 };
 // (every cell a ray can reach lies within max_iter cells of the start cell)
 struct TiledWin
 {
+    enum { DEFER = 0 };
     uint8_t* pool;
     int32_t* tab;  // this particle's table in HBM
     int32_t* win;  // LDS window: entry (a, b) = table entry of tile (ti0 + a, tj0 + b), 0 outside the canvas
@@ -108,9 +109,9 @@ struct TiledWin
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return Cow{wmask, e, ptr};
     }
-    // literal fallback only: one cell, every lane the same
-    __device__ __forceinline__ uint8_t load1(int i, int j) const { return *cell_ptr(win[slot(i, j)], i, j); }
-    __device__ __forceinline__ void store1(bool wr, int i, int j, uint8_t v, int lane) const
+    // literal fallback only: one cell, every lane the same (ks: the sample's number, for TiledDefer)
+    __device__ __forceinline__ uint8_t load1(int i, int j, int) const { return *cell_ptr(win[slot(i, j)], i, j); }
+    __device__ __forceinline__ void store1(bool wr, int i, int j, uint8_t v, int lane, int) const
     {
         uint64_t w = __ballot(wr);
         const int e = win[slot(i, j)];
@@ -126,8 +127,53 @@ struct TiledWin
     }
 };
 
+// Weights now, canvas later (round 3).  At the sizes that matter nearly every particle dies at the resample that follows
+// its weighting pass (bench shard: 125 000 particles, 2-9 % distinct ancestors), yet each first copied the ~45 tiles its
+// scan writes: 46 GB per step for canvases nobody keeps.  This map writes nothing to memory: it reads the particle's tiles
+// as they are and keeps the pass's own writes only where a LATER ray of the same scan can read them, a square window of
+// LDS around the sensor.  That is exact: two rays from one origin whose directions differ by at least `gap` pass more than
+// sqrt(2) apart (no common cell) beyond sqrt(2) / sin(gap) cells from the origin, so every cell that two rays of the scan
+// touch is touched at samples <= kstar by both, where kstar = that range plus margin, computed by the host from the scan's
+// smallest angular gap; all samples <= kstar read and write the window, all later ones read memory and drop their writes.
+// The canvases of the particles the resample SELECTS are then brought up to date by running the ordinary kernel (with its
+// copy-on-write copies) on those particles alone, before their tables are handed to their children: same statements on
+// the same inputs, same canvases.
+struct TiledDefer
+{
+    enum { DEFER = 1 };
+    const uint8_t* pool;
+    const int32_t* win;  // LDS window of the table (read only), as in TiledWin
+    int ti0, tj0, W;
+    uint8_t* pw;         // LDS: Wd x Wd cells, cell (i, j) at pw[(i - wi0) * Wd + (j - wj0)]
+    int wi0, wj0, Wd, kstar;
+    struct Cow
+    {
+        uint64_t wmask;
+        int e;
+        uint8_t* ptr;
+    };
+    __device__ __forceinline__ int slot(int i, int j) const { return ((i >> TILE_SHIFT) - ti0) * W + ((j >> TILE_SHIFT) - tj0); }
+    __device__ __forceinline__ uint8_t* cell_ptr(int e, int i, int j) const
+    {
+        return const_cast<uint8_t*>(pool) + (((size_t)(unsigned)(e & ~TILE_OWN) << 12) | (size_t)(unsigned)tile_cell(i, j));
+    }
+    __device__ __forceinline__ int entry(bool ok, int i, int j) const { return win[ok ? slot(i, j) : 0]; }
+    __device__ __forceinline__ bool owned(int) const { return true; }
+    __device__ __forceinline__ Cow cow(uint64_t, uint64_t wmask, int, int, int e, uint8_t* ptr, int) const { return Cow{wmask, e, ptr}; }
+    __device__ __forceinline__ int pwi(int i, int j) const { return (i - wi0) * Wd + (j - wj0); }
+    __device__ __forceinline__ uint8_t load1(int i, int j, int ks) const
+    {
+        return ks <= kstar ? pw[pwi(i, j)] : *cell_ptr(win[slot(i, j)], i, j);
+    }
+    __device__ __forceinline__ void store1(bool wr, int i, int j, uint8_t v, int, int ks) const
+    {
+        if (wr && ks <= kstar) pw[pwi(i, j)] = v;
+    }
+};
+
 struct DenseS2
 {
+    enum { DEFER = 0 };
     uint8_t* base;
     int cols;
     struct Cow
@@ -144,8 +190,8 @@ struct DenseS2
         return base + ((e & 1) ? (size_t)i * (size_t)cols + (size_t)j : (size_t)0);
     }
     __device__ __forceinline__ Cow cow(uint64_t, uint64_t wmask, int, int, int e, uint8_t* ptr, int) const { return Cow{wmask, e, ptr}; }
-    __device__ __forceinline__ uint8_t load1(int i, int j) const { return *cell_ptr(1, i, j); }
-    __device__ __forceinline__ void store1(bool wr, int i, int j, uint8_t v, int) const
+    __device__ __forceinline__ uint8_t load1(int i, int j, int) const { return *cell_ptr(1, i, j); }
+    __device__ __forceinline__ void store1(bool wr, int i, int j, uint8_t v, int, int) const
     {
         if (wr) *cell_ptr(1, i, j) = v;
     }
@@ -176,7 +222,7 @@ __device__ __noinline__ void s2_literal(const MAP& map, int rows, int cols, doub
         slam_cell_of(rows, x, y, &i, &j);
         if (i == pi && j == pj) continue;
         if (!slam_in_bounds(rows, cols, i, j)) break;
-        const uint8_t c = map.load1(i, j);
+        const uint8_t c = map.load1(i, j, it + 1);
         out->n_read++;
         if (!found && c < 128)
         {
@@ -203,7 +249,7 @@ __device__ __noinline__ void s2_literal(const MAP& map, int rows, int cols, doub
             }
             drew = true;
         }
-        map.store1(wr && lane == 0, i, j, v, lane);
+        map.store1(wr && lane == 0, i, j, v, lane, it + 1);
         if (wr) out->n_written++;
         if (d2 >= zmax2) break;
         pi = i;
@@ -221,7 +267,8 @@ __device__ __forceinline__ int s2_first(uint64_t m) { return m ? __builtin_ctzll
 template <bool STATS, class MAP>
 __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bits + q, stride 64 per pass */, int rows, int cols,
                                       int i0, int j0, int si, int sj, int k_far, int k_vfar, bool draw_occ, int max_iter,
-                                      const uint8_t* luts, int lane, unsigned* n_read, unsigned* n_written, unsigned* n_steps)
+                                      const uint8_t* luts, int lane, unsigned* n_read, unsigned* n_written, unsigned* n_steps,
+                                      bool* ended = nullptr /* out: the ray ended within max_iter samples (k_weights_S2F passes 64) */)
 {
     const int npass = (max_iter + 63) / 64;
     const int Lfar = k_far - 1, Lvfar = k_vfar - 1;  // as bit numbers: sample k is bit k - 1 of the ray
@@ -260,9 +307,17 @@ __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bit
                 oob[u] = N & ~INB;
                 ci[u] = i;
                 cj[u] = j;
-                ent[u] = map.entry(__builtin_amdgcn_inverse_ballot_w64(cand[u]), i, j);
+                const bool have = __builtin_amdgcn_inverse_ballot_w64(cand[u]);
+                ent[u] = map.entry(have, i, j);
                 ptr[u] = map.cell_ptr(ent[u], i, j);
-                cv[u] = *ptr[u];
+                if constexpr (MAP::DEFER)
+                {
+                    // samples up to kstar live in the LDS window (they may meet another ray's cells), later ones in memory
+                    const bool near = (g + u) * 64 + lane + 1 <= map.kstar;
+                    cv[u] = near ? map.pw[have ? map.pwi(i, j) : 0] : *ptr[u];
+                }
+                else
+                    cv[u] = *ptr[u];
                 base_r += __builtin_popcountll(R);
                 base_c += __builtin_popcountll(C);
             }
@@ -342,7 +397,14 @@ __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bit
                     W = r.wmask;
                     to = r.ptr;
                 }
-                if (__builtin_amdgcn_inverse_ballot_w64(W)) *to = v;
+                if constexpr (MAP::DEFER)
+                {
+                    // (writes beyond kstar are dropped: no ray of this scan reads those cells again, and the canvas is
+                    // brought up to date after the resample, for the particles that survive it)
+                    if (__builtin_amdgcn_inverse_ballot_w64(W) && G0 + lane + 1 <= map.kstar) map.pw[map.pwi(ci[u], cj[u])] = v;
+                }
+                else if (__builtin_amdgcn_inverse_ballot_w64(W))
+                    *to = v;
                 if (STATS) writes += (unsigned)__builtin_popcountll(W);
             }
         }
@@ -354,6 +416,7 @@ __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bit
         *n_written += writes;
         *n_steps += steps;
     }
+    if (ended) *ended = done;
     return khit;
 }
 
@@ -362,15 +425,25 @@ __device__ __forceinline__ int s2_ray(const MAP& map, const uint4* bits_q /* bit
 #ifndef S2_WAVES
 #define S2_WAVES 4
 #endif
-template <bool TILED, bool STATS = true>
-__global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2(WeightArgs a, TileArgs ta, int npass, int win_w, int force_literal)
+// DEFER (tiles only): weights now, canvases later: see TiledDefer; dk = kstar, dw = side of its LDS window (a multiple of 8).
+// sub (the pass that brings the survivors' canvases up to date): block b works on particle sub.list[b], blocks from
+// *sub.count on have nothing to do.
+struct S2Subset
+{
+    const int32_t* list;
+    const int* count;
+};
+template <bool TILED, bool STATS = true, bool DEFER = false>
+__global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2(WeightArgs a, TileArgs ta, int npass, int win_w, int force_literal,
+                                                             S2Subset sub, int dk, int dw)
 {
     extern __shared__ __align__(16) unsigned char s2_lds[];
     uint8_t* luts = s2_lds;                                // free table, occupied table
     uint4* bits = reinterpret_cast<uint4*>(s2_lds + 512);  // [npass][64 beams]: {R lo, R hi, C lo, C hi}
     int32_t* win = reinterpret_cast<int32_t*>(s2_lds + 512 + (size_t)npass * 1024);
     const int lane = threadIdx.x;
-    const int64_t p = blockIdx.x;
+    if (sub.list && (int)blockIdx.x >= *sub.count) return;
+    const int64_t p = sub.list ? (int64_t)sub.list[blockIdx.x] : (int64_t)blockIdx.x;
     for (int t = lane; t < 512; t += 64) luts[t] = a.luts[t];
     const double px = a.x[p], py = a.y[p], pth = a.th[p];
     double s0, c0;
@@ -378,14 +451,16 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2(WeightArgs a, TileA
     const double sx = px + c0 * a.sd;
     const double sy = py + s0 * a.sd;
     const double rows_d = (double)a.rows;
+    if (DEFER && !slam_defer_safe(sx, sy, rows_d, a.defer_edge)) return;  // this particle takes the ordinary pass (k_defer_split)
     int i0, j0;
     slam_cell_of(a.rows, sx, sy, &i0, &j0);
     const DenseS2 dmap = {a.grid + a.map_stride * (size_t)p, a.cols};
     TiledWin tmap = {ta.pool, nullptr, win, 0, 0, win_w, ta.tcols, ta.freelist, ta.ctrl};
+    TiledDefer fmap = {ta.pool, win, 0, 0, win_w, s2_lds + 512 + (size_t)npass * 1024 + (size_t)win_w * win_w * 4, 0, 0, dw, dk};
     if (TILED)
     {
         tmap.tab = ta.tab + (size_t)p * ta.tiles_per_map;
-        if (ta.plan_rng)
+        if (!DEFER && ta.plan_rng)
         {
             // The deferred deep copy of slam/mcl.cpp:147-155, made here instead of by k_tile_copy: the tiles k_tile_plan
             // listed for this particle are copied by its own wavefront, four tiles (16 loads of 16 bytes per lane) in
@@ -455,6 +530,26 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2(WeightArgs a, TileA
         {
             const int ti = tmap.ti0 + t / win_w, tj = tmap.tj0 + t % win_w;
             win[t] = (ti >= 0 && tj >= 0 && ti < trows && tj < ta.tcols) ? tmap.tab[ti * ta.tcols + tj] : 0;
+        }
+        if (DEFER)
+        {
+            // the canvas around the sensor into LDS, eight cells (one row of an 8x8 micro-block) per load; the origin is
+            // a multiple of 8 in both directions and every cell of the samples 1..kstar lies inside (host: dw)
+            fmap.ti0 = tmap.ti0;
+            fmap.tj0 = tmap.tj0;
+            fmap.wi0 = (ci - dk - 2) & ~7;
+            fmap.wj0 = (cj - dk - 2) & ~7;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int per_row = dw >> 3;
+            for (int t = lane; t < dw * per_row; t += 64)
+            {
+                const int r = t / per_row, i = fmap.wi0 + r, j = fmap.wj0 + ((t - r * per_row) << 3);
+                uint64_t v = 0;
+                if (i >= 0 && i < a.rows && j >= 0 && j < a.cols)  // (j is a multiple of 8: the tile of (i, j) holds (i, j + 7) as well)
+                    v = *reinterpret_cast<const uint64_t*>(fmap.cell_ptr(win[fmap.slot(i, j)], i, j));
+                *reinterpret_cast<uint64_t*>(fmap.pw + (size_t)r * dw + ((t - r * per_row) << 3)) = v;
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -574,7 +669,10 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2(WeightArgs a, TileA
             if (literal)
             {
                 WaveRay wr;
-                if (TILED)
+                if (TILED && DEFER)
+                    s2_literal(fmap, a.rows, a.cols, sx, sy, bcast_f64(dx, q), bcast_f64(dy, q), bcast_f64(z2, q), a.zmax2, luts,
+                               luts + 256, max_iter, lane, &wr);
+                else if (TILED)
                     s2_literal(tmap, a.rows, a.cols, sx, sy, bcast_f64(dx, q), bcast_f64(dy, q), bcast_f64(z2, q), a.zmax2, luts,
                                luts + 256, max_iter, lane, &wr);
                 else
@@ -595,7 +693,10 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2(WeightArgs a, TileA
                 unsigned r = 0, w = 0, st = 0;
                 const bool draw_occ = bcast_f64(z2, q) != a.zmax2;  // slam/raycast.cpp:205
                 int khit;
-                if (TILED)
+                if (TILED && DEFER)
+                    khit = s2_ray<STATS>(fmap, bits + q, a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
+                                  bcast_i32(k_vfar, q), draw_occ, max_iter, luts, lane, &r, &w, &st);
+                else if (TILED)
                     khit = s2_ray<STATS>(tmap, bits + q, a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
                                   bcast_i32(k_vfar, q), draw_occ, max_iter, luts, lane, &r, &w, &st);
                 else
@@ -656,5 +757,293 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2(WeightArgs a, TileA
             atomicAdd(&a.stats[2], n_steps);
         }
     }
+}
+
+// ---- weights only, fast (round 3): the first half of a deferred update (TiledDefer) without the counters -----------------
+// With the canvases left alone, the rays of a scan depend on each other only through the LDS window, i.e. through their
+// first kstar < 64 samples.  So only the FIRST pass of 64 samples of every ray runs in beam order (s2_ray on one pass: the
+// window is read and written there exactly as the full kernel would); whatever is left of a ray after that is a search
+// for its first occupied cell that no other ray can influence, and 64 rays run it side by side, lane = beam, with the
+// literal x += dx; y += dy of slam/raycast.cpp:165-166 and eight samples' cells in flight per round trip to memory:
+//   new cell (slam/raycast.cpp:171-174) -> left the grid: no hit (:176) -> below 128: the hit (:183-189) -> at or beyond
+//   max_dist: no hit (:216).
+// (The loop of :163 can end earlier only once a hit has been found, and the free / occupied updates are the canvas's
+// business, which the second half of the deferred update settles for the survivors.)  The geometry phase shrinks to
+// one pass as well.  Same hits, same weights, bit for bit, as k_weights_S2<true, false, true>.
+// Measured (125 000 x 90): that kernel 16.7 ms, this one 11.8 ms.  Tried and dropped: ordering only the first
+// kstar samples (the search grows: +1.2 ms); searching with lane = sample over the geometry bits of all passes, one ray or
+// four side by side (fewer vector instructions, 38 000 against 41 000 per particle, but 26 000 scalar ones: 13.2 ms).
+enum { S2F_U = 8 };
+__global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2F(WeightArgs a, TileArgs ta, int win_w, int force_literal, int dk, int dw)
+{
+    extern __shared__ __align__(16) unsigned char s2_lds[];
+    uint8_t* luts = s2_lds;                                // free table, occupied table
+    uint4* bits = reinterpret_cast<uint4*>(s2_lds + 512);  // [64 beams]: the first 64 samples
+    int32_t* win = reinterpret_cast<int32_t*>(s2_lds + 512 + 1024);
+    const int lane = threadIdx.x;
+    const int64_t p = blockIdx.x;
+    for (int t = lane; t < 512; t += 64) luts[t] = a.luts[t];
+    const double px = a.x[p], py = a.y[p], pth = a.th[p];
+    double s0, c0;
+    dm_sincos(pth + a.stheta, &s0, &c0);
+    const double sx = px + c0 * a.sd;
+    const double sy = py + s0 * a.sd;
+    const double rows_d = (double)a.rows;
+    if (!slam_defer_safe(sx, sy, rows_d, a.defer_edge)) return;  // this particle takes the ordinary pass (k_defer_split)
+    int i0, j0;
+    slam_cell_of(a.rows, sx, sy, &i0, &j0);
+    const int32_t* tab = ta.tab + (size_t)p * ta.tiles_per_map;
+    TiledDefer fmap = {ta.pool, win, 0, 0, win_w, s2_lds + 512 + 1024 + (size_t)win_w * win_w * 4, 0, 0, dw, dk};
+    const int max_iter = a.max_iter;
+    const int reach = ((max_iter + 63) / 64) * 64;
+    {
+        const int ci = i0 < -(1 << 24) ? -(1 << 24) : (i0 > (1 << 24) ? (1 << 24) : i0);
+        const int cj = j0 < -(1 << 24) ? -(1 << 24) : (j0 > (1 << 24) ? (1 << 24) : j0);
+        fmap.ti0 = (ci - reach) >> TILE_SHIFT;
+        fmap.tj0 = (cj - reach) >> TILE_SHIFT;
+        const int trows = ta.tiles_per_map / ta.tcols;
+        for (int t = lane; t < win_w * win_w; t += 64)
+        {
+            const int ti = fmap.ti0 + t / win_w, tj = fmap.tj0 + t % win_w;
+            win[t] = (ti >= 0 && tj >= 0 && ti < trows && tj < ta.tcols) ? tab[ti * ta.tcols + tj] : 0;
+        }
+        fmap.wi0 = (ci - dk - 2) & ~7;
+        fmap.wj0 = (cj - dk - 2) & ~7;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int per_row = dw >> 3;
+        for (int t = lane; t < dw * per_row; t += 64)
+        {
+            const int r = t / per_row, i = fmap.wi0 + r, j = fmap.wj0 + ((t - r * per_row) << 3);
+            uint64_t v = 0;
+            if (i >= 0 && i < a.rows && j >= 0 && j < a.cols)
+                v = *reinterpret_cast<const uint64_t*>(fmap.cell_ptr(win[fmap.slot(i, j)], i, j));
+            *reinterpret_cast<uint64_t*>(fmap.pw + (size_t)r * dw + ((t - r * per_row) << 3)) = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int first_n = max_iter < 64 ? max_iter : 64;  // samples of the ordered first pass
+    double acc = 0.0;
+    for (int b0 = 0; b0 < a.B; b0 += 64)
+    {
+        const int b = b0 + lane;
+        const int cnt = (a.B - b0) < 64 ? (a.B - b0) : 64;
+        double dx = 0.0, dy = 0.0, z2 = 0.0;
+        if (b < a.B)
+        {
+            dm_sincos(pth + a.angles[b] + a.srot, &dy, &dx);
+            z2 = a.z2[b];
+        }
+        // ---- geometry of the first 64 samples, lane = beam (as phase A of k_weights_S2, one pass) ----
+        int k_far, k_vfar, si, sj, kl;
+        bool regular;
+        double xl, yl, x64, y64;
+        int ci64, cj64;
+        {
+            double x = sx, y = sy;
+            int pi = i0, pj = j0;
+            double xf = sx, yf = sy, xv = sx, yv = sy;
+            int kf = 0, kv = 0;
+            uint32_t w[4];
+            unsigned cnt_r = 0, cnt_c = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+            {
+                uint32_t par_r = 0, par_c = 0;
+                const uint32_t before_r = (uint32_t)pi & 1u, before_c = (uint32_t)pj & 1u;
+#pragma unroll
+                for (int s = 0; s < 32; ++s)
+                {
+                    x += dx;
+                    y += dy;
+                    const int ni = slam_f2i((rows_d - y) - 1.0), nj = slam_f2i(x);
+                    par_r = __builtin_amdgcn_alignbit((uint32_t)ni, par_r, 1);
+                    par_c = __builtin_amdgcn_alignbit((uint32_t)nj, par_c, 1);
+                    pi = ni;
+                    pj = nj;
+                    if ((s & 15) == 15)
+                    {
+                        const double ex = x - sx, ey = y - sy;
+                        const double d2 = ex * ex + ey * ey;
+                        const int k = h * 32 + s + 1;
+                        if (d2 < z2)
+                        {
+                            xf = x;
+                            yf = y;
+                            kf = k;
+                        }
+                        if (d2 < a.zmax2)
+                        {
+                            xv = x;
+                            yv = y;
+                            kv = k;
+                        }
+                    }
+                }
+                const uint32_t rw = par_r ^ ((par_r << 1) | before_r), cw = par_c ^ ((par_c << 1) | before_c);
+                w[h] = rw;
+                w[2 + h] = cw;
+                cnt_r += (unsigned)__builtin_popcount(rw);
+                cnt_c += (unsigned)__builtin_popcount(cw);
+            }
+            if (max_iter < 64)
+            {  // samples beyond max_iter do not exist
+                const uint64_t keep = s2_below(max_iter);
+                w[0] &= (uint32_t)keep;
+                w[1] &= (uint32_t)(keep >> 32);
+                w[2] &= (uint32_t)keep;
+                w[3] &= (uint32_t)(keep >> 32);
+            }
+            bits[lane] = make_uint4(w[0], w[1], w[2], w[3]);
+            const int di = pi - i0, dj = pj - j0;
+            regular = (unsigned)(di < 0 ? -di : di) == cnt_r && (unsigned)(dj < 0 ? -dj : dj) == cnt_c;
+            si = di > 0 ? 1 : (di < 0 ? -1 : 0);
+            sj = dj > 0 ? 1 : (dj < 0 ? -1 : 0);
+            x64 = x;
+            y64 = y;
+            ci64 = pi;
+            cj64 = pj;
+            const int none = 65;
+            k_far = none;
+            k_vfar = none;
+            xl = xf;
+            yl = yf;
+            kl = kf;
+#pragma unroll 4
+            for (int s = 1; s <= 16; ++s)
+            {
+                xf += dx;
+                yf += dy;
+                xv += dx;
+                yv += dy;
+                const double ex = xf - sx, ey = yf - sy;
+                if (!(ex * ex + ey * ey < z2) && k_far == none && kf + s <= 64) k_far = kf + s;
+                const double fx = xv - sx, fy = yv - sy;
+                if (!(fx * fx + fy * fy < a.zmax2) && k_vfar == none && kv + s <= 64) k_vfar = kv + s;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const bool literal = force_literal || __ballot(!regular && b < a.B) != 0;
+        // ---- the first pass of every ray, beams in order, lane = sample ----
+        int my_khit = 0;
+        bool my_ended = true;
+        slam_ray_result mine = {-1.0, -1.0, -1};
+        for (int q = 0; q < cnt; ++q)
+        {
+            if (literal)
+            {
+                WaveRay wr;
+                s2_literal(fmap, a.rows, a.cols, sx, sy, bcast_f64(dx, q), bcast_f64(dy, q), bcast_f64(z2, q), a.zmax2, luts, luts + 256,
+                           max_iter, lane, &wr);
+                if (lane == q)
+                {
+                    mine.hx = wr.hx;
+                    mine.hy = wr.hy;
+                    mine.hcell = wr.hcell;
+                }
+            }
+            else
+            {
+                unsigned r = 0, w = 0, st = 0;
+                bool ended;
+                const bool draw_occ = bcast_f64(z2, q) != a.zmax2;  // slam/raycast.cpp:205
+                const int khit = s2_ray<false>(fmap, bits + q, a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
+                                               bcast_i32(k_vfar, q), draw_occ, first_n, luts, lane, &r, &w, &st, &ended);
+                if (lane == q)
+                {
+                    my_khit = khit;
+                    my_ended = ended;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        // ---- lane = beam: hits of the first pass re-walked from their latch; rays still searching go on from sample 65 ----
+        if (!literal)
+        {
+            const bool from_latch = my_khit >= kl;
+            double hx = from_latch ? xl : sx, hy = from_latch ? yl : sy;
+            const int todo = my_khit - (from_latch ? kl : 0);
+            for (int k = 1; __ballot(k <= todo) != 0; ++k)
+                if (k <= todo)
+                {
+                    hx += dx;
+                    hy += dy;
+                }
+            if (my_khit > 0)
+            {
+                mine.hx = hx;
+                mine.hy = hy;
+                int hi, hj;
+                slam_cell_of(a.rows, hx, hy, &hi, &hj);
+                mine.hcell = hi * a.cols + hj;
+            }
+            bool go = b < a.B && my_khit == 0 && !my_ended && max_iter > 64;
+            double x = x64, y = y64;
+            int pi = ci64, pj = cj64;
+            for (int k0 = 64; __ballot(go) != 0; k0 += S2F_U)
+            {
+                double xs[S2F_U], ys[S2F_U];
+                int is[S2F_U], js[S2F_U];
+                uint8_t cv[S2F_U];
+#pragma unroll
+                for (int u = 0; u < S2F_U; ++u)
+                {
+                    x += dx;
+                    y += dy;
+                    xs[u] = x;
+                    ys[u] = y;
+                    is[u] = slam_f2i((rows_d - y) - 1.0);
+                    js[u] = slam_f2i(x);
+                    const bool ok = go && k0 + u + 1 <= max_iter && slam_in_bounds(a.rows, a.cols, is[u], js[u]);
+                    cv[u] = *fmap.cell_ptr(fmap.entry(ok, is[u], js[u]), ok ? is[u] : 0, ok ? js[u] : 0);
+                }
+#pragma unroll
+                for (int u = 0; u < S2F_U; ++u)
+                {
+                    if (go)
+                    {
+                        if (k0 + u + 1 > max_iter)
+                            go = false;  // slam/raycast.cpp:163 with the sample bound of the walk
+                        else if (is[u] != pi || js[u] != pj)
+                        {
+                            if (!slam_in_bounds(a.rows, a.cols, is[u], js[u]))
+                                go = false;  // :176
+                            else if (cv[u] < 128)
+                            {  // :183-189
+                                mine.hx = xs[u];
+                                mine.hy = ys[u];
+                                mine.hcell = is[u] * a.cols + js[u];
+                                go = false;
+                            }
+                            else
+                            {
+                                const double ex = xs[u] - sx, ey = ys[u] - sy;
+                                if (ex * ex + ey * ey >= a.zmax2) go = false;  // :216
+                                pi = is[u];
+                                pj = js[u];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        double lw = 0.0;
+        if (b < a.B)
+        {
+            lw = slam_beam_logw(&mine, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps);
+            if (a.hit_xy)
+            {
+                const size_t o = (size_t)p * a.B + b;
+                a.hit_xy[2 * o] = mine.hx;
+                a.hit_xy[2 * o + 1] = mine.hy;
+                a.hit_cell[o] = mine.hcell;
+            }
+        }
+        for (int l = 0; l < cnt; ++l) acc += readlane_f64(lw, l);
+    }
+    if (lane == 0) a.w[p] = a.log_domain ? acc : dm_exp(acc);
 }
 }  // namespace slamk

@@ -282,6 +282,12 @@ class Filter:
         check(self.lib.slam_mcl_get_tile_stats(self._h, ptr(out)), self.lib)
         return {"pool": int(out[0]), "live": int(out[1]), "allocated_since": int(out[2])}
 
+    def defer_stats(self):
+        """Tiled canvases: how many updates left their canvases for the resample that followed (include/slam_hip.h)."""
+        out = np.zeros(3, dtype=np.int64)
+        check(self.lib.slam_mcl_get_defer_stats(self._h, ptr(out)), self.lib)
+        return {"updates": int(out[0]), "deferred": int(out[1]), "edge_particles": int(out[2])}
+
     def profile(self, enable=True):
         """True / 1: an event pair around every kernel group; 2: the weighting pass only, timed on its kernels' own
         dispatch timestamps where the path allows (no event records between the kernels); False / 0: off."""
