@@ -550,6 +550,18 @@ def main():
     barrier()
     groups = f.kernel_ms()
     f.profile(False)
+    # what a step costs the HOST: three steps enqueued on an idle GPU (fewer than the four the scan ring lets the host run
+    # ahead, so that nothing here waits for the device; over the 20 timed steps the host is throttled to the GPU's pace by
+    # that ring, and host_enqueue_ms_per_step only says that it kept up)
+    step_no[0] = max(0, len(scans) - 3)
+    torch.cuda.synchronize()
+    th0 = time.perf_counter()
+    for _ in range(3):
+        step_predict()
+        step_update()
+    host_own = (time.perf_counter() - th0) / 3 * 1e3
+    torch.cuda.synchronize()
+    barrier()
 
     if rank == 0:
         # how collapsed the timed cloud is: ancestors of the last resample and the spread of the poses
@@ -614,6 +626,9 @@ def main():
             "kernel_ms_per_step_note": "from a second pass of the same steps after the timed region, every group bracketed by HIP events "
                                        "(the timed region itself carries only the weighting pass's two events)",
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
+            "host_cost_ms_per_step": host_own,
+            "host_note": "host_enqueue_ms_per_step: wall time of the enqueue loop of the timed region (the scan ring lets the host run at most "
+                         "4-8 steps ahead, so it tracks the GPU); host_cost_ms_per_step: the host's own time to enqueue a step (3 steps on an idle GPU)",
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(free, ang, dscan, B)
