@@ -186,7 +186,8 @@ int slam_mcl_get_kernel_ms(slam_mcl* h, double ms[5], int64_t launches[5], int32
 typedef struct slam_mcl_device_state
 {
     double* state_dev;       /* 4 * n_particles doubles */
-    double* prefix_dev;      /* global_n inclusive running sums of the last resample */
+    double* prefix_dev;      /* global_n inclusive running sums of the last resample before this call (a later resample of
+                              * 4097..262144 particles selects without writing them out: call again, or slam_mcl_get_prefix) */
     int64_t n_particles;
     int64_t global_n;
 } slam_mcl_device_state;

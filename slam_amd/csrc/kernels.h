@@ -1071,14 +1071,84 @@ struct SelectArgs
     StateView view;         // sort keys wanted (keys != nullptr): weight of the particle selected for slot k,
     double* keys;           // payload k
     int32_t* slots;
+    // k_select<true> only: P is not materialised; s0 = scans inside the 64-chunks of the weights, tot0 = the n1 chunk totals
+    const double *s0, *tot0;
+    int n1;
 };
+enum { SELECT_FUSED_MAX_N1 = 4096 };
 
 // slam/mcl.cpp:179-203: cutoff = canonical * sum; bisection in which equality returns mid.
+// FUSED (three-level hierarchies, 4096 < n_total <= 262144): the running sums are never written out.  Every workgroup
+// rebuilds the upper levels from the chunk totals in LDS (the operations of k_scan_upper, in its order: at most 4096
+// totals, a microsecond), and a probe forms P[mid] = P1[mid / 64 - 1] + s0[mid] as k_downsweep would have: the same
+// doubles, two launches fewer per step (k_scan_upper, k_downsweep).  slam_mcl_get_prefix completes the array on demand.
+template <bool FUSED>
 __global__ void __launch_bounds__(256) k_select(SelectArgs a)
 {
+    __shared__ double P1[FUSED ? SELECT_FUSED_MAX_N1 : 1];
+    __shared__ double tot1[FUSED ? 64 : 1];
+    if (FUSED)
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int n1 = a.n1;
+        // (four chunks of a wavefront side by side: the scan of one chunk is a chain of six cross-lane steps)
+        for (int c0 = wave * 4; c0 * 64 < n1; c0 += 16)
+        {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+                const int i = (c0 + u) * 64 + lane;
+                v[u] = i < n1 ? a.tot0[i] : 0.0;
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const double t = __shfl_up(v[u], d, 64);
+                    if (lane >= d) v[u] = t + v[u];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+                const int c = c0 + u, i = c * 64 + lane;
+                if (i < n1) P1[i] = v[u];  // s1 for now
+                const int last = (c * 64 + 63 < n1 - 1) ? c * 64 + 63 : n1 - 1;
+                if (i == last) tot1[c] = v[u];
+            }
+        }
+        __syncthreads();
+        const int n2 = (n1 + 63) >> 6;  // <= 64: one chunk, its scan is P2
+        double v2 = 0.0;
+        if (wave == 0)
+        {
+            v2 = lane < n2 ? tot1[lane] : 0.0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1)
+            {
+                const double t = __shfl_up(v2, d, 64);
+                if (lane >= d) v2 = t + v2;
+            }
+        }
+        __syncthreads();
+        if (wave == 0 && lane < n2) tot1[lane] = v2;
+        __syncthreads();
+        for (int j = threadIdx.x; j < n1; j += 256)
+        {
+            const int c = j >> 6;
+            if (c) P1[j] = tot1[c - 1] + P1[j];
+        }
+        __syncthreads();
+    }
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.n_slots) return;
-    const double sum = a.P[a.n_total - 1];
+    auto P = [&](int m) -> double {
+        if (!FUSED) return a.P[m];
+        const int c = m >> 6;
+        return c ? P1[c - 1] + a.s0[m] : a.s0[m];
+    };
+    const double sum = P((int)a.n_total - 1);
     double cutoff;
     if (a.resampler == 0)
     {
@@ -1095,7 +1165,7 @@ __global__ void __launch_bounds__(256) k_select(SelectArgs a)
     while (i < j)
     {
         const int mid = i + (j - i) / 2;
-        const double c = a.P[mid];
+        const double c = P(mid);
         if (c == cutoff)
         {
             i = mid;
@@ -1130,6 +1200,29 @@ __global__ void __launch_bounds__(256) k_gather(StateView view, const int32_t* i
     dst[3 * n + p] = view.wbase ? view.wbase[s] : from[3 * view.n_loc];
     src[p] = s;
 }
+
+// The same for ONE output position, as the epilogue of the weight sort's last kernel (sortk::k_ss_buckets): position p of
+// the sorted order holds slot `slot` of the selection.
+struct GatherEpilogue
+{
+    StateView view;
+    const int32_t* idx;
+    int64_t n;
+    double* dst;
+    int32_t* src;
+    __device__ __forceinline__ void operator()(int p, int32_t slot) const
+    {
+        const int32_t s = idx[slot];
+        const int64_t r = s / view.n_loc;
+        const int64_t o = s - r * view.n_loc;
+        const double* from = view.base + r * (view.wbase ? 3 : 4) * view.n_loc + o;
+        dst[p] = from[0];
+        dst[n + p] = from[view.n_loc];
+        dst[2 * n + p] = from[2 * view.n_loc];
+        dst[3 * n + p] = view.wbase ? view.wbase[s] : from[3 * view.n_loc];
+        src[p] = s;
+    }
+};
 
 // slam/mcl.cpp:147-155: deep copy of each selected particle's map.  grid = (particles, chunks).
 // Also packs maps for the sharded exchange (dst slot p <- src map src[p]).

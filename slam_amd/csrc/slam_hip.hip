@@ -135,6 +135,7 @@ struct slam_mcl
     // resampling
     std::vector<int64_t> lvl_n;
     std::vector<double*> lvl_s, lvl_P, lvl_tot;  // lvl_tot[l] = input array of level l+1
+    bool prefix_partial = false;                 // the last selection was k_select<true>: lvl_P[0] is not written yet (complete_prefix)
     int32_t *idx = nullptr, *perm = nullptr, *slots = nullptr, *src = nullptr;
     double *keys = nullptr, *keys2 = nullptr;
     void* sort_tmp = nullptr;
@@ -267,6 +268,8 @@ struct Tuning
     int tile_fuse;   // SLAM_TILE_FUSE: 1 = the two-phase kernel makes the planned tile copies itself (default), 0 = k_tile_copy before it
     int defer;       // SLAM_DEFER: grid-SLAM update on tiles, "weights now, canvases of the survivors later" (TiledDefer, slam_s2.h):
                      // 0 = never, 1 = when the last resample kept fewer than half of the particles (default), 2 = whenever the scan allows
+    int select_fuse; // SLAM_SELECT_FUSE: 1 = 4097..262144 particles: k_select rebuilds the upper levels of the running sum itself and the weight
+                     // sort's last kernel gathers the states (default: three launches fewer per step), 0 = k_scan_upper + k_downsweep, k_gather
     int defer_fast;  // SLAM_DEFER_FAST: 1 = the weights-only kernel k_weights_S2F for the first half (default), 0 = k_weights_S2<DEFER>
 };
 const Tuning& tuning()
@@ -277,7 +280,7 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 4 | (7 << 4) | (8 << 8)), env_int("SLAM_PL_ORDER_SPARSE", 4 | (7 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1), env_int("SLAM_DEFER", 1), env_int("SLAM_DEFER_FAST", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 4 | (7 << 4) | (8 << 8)), env_int("SLAM_PL_ORDER_SPARSE", 4 | (7 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1), env_int("SLAM_DEFER", 1), env_int("SLAM_SELECT_FUSE", 1), env_int("SLAM_DEFER_FAST", 1)};
     return t;
 }
 
@@ -300,12 +303,19 @@ int rocprim_scratch(void** tmp, size_t* have, size_t need)
     return SLAM_OK;
 }
 
-int sort_by_weight(slam_mcl* h, int64_t n)
+// gather: the sample sort's last kernel also gathers the particle states (slamk::GatherEpilogue); *gathered says whether it did
+int sort_by_weight(slam_mcl* h, int64_t n, const slamk::GatherEpilogue* gather = nullptr, bool* gathered = nullptr)
 {
+    if (gathered) *gathered = false;
     if (tuning().sort_impl & 1)
     {
         if (n <= sortk::SMALL_MAX)
             sortk::small_sort_pairs(h->keys, h->slots, h->perm, n, h->stream);
+        else if (n <= sortk::MAX_N && gather && gathered && tuning().select_fuse != 0)
+        {
+            sortk::sort_pairs(h->ss_tmp, h->keys, h->slots, h->perm, n, false, h->stream, tuning().ss_lds_cap, *gather);
+            *gathered = true;
+        }
         else if (n <= sortk::MAX_N)
             sortk::sort_pairs(h->ss_tmp, h->keys, h->slots, h->perm, n, false, h->stream, tuning().ss_lds_cap);
         else
@@ -897,14 +907,18 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
 // Canonical blocked running sum of `in` (nullptr: the weight column of `view`) into u.P[0].
 // u.n[l] = entries of level l (n[0] = all weights, n[l+1] = ceil(n[l] / 64), the last level holds <= 64);
 // the top level's P is its s (same buffer).  Launches only; allocates nothing.
-void launch_blocked_prefix(hipStream_t stream, const double* in, const slamk::StateView& view, const slamk::UpperLevels& u)
+// part: 0 = all of it; 1 = the scans inside the 64-chunks of the weights only (k_select<true> rebuilds the rest for itself);
+// 2 = what part 1 left out (slam_mcl_get_prefix after such a selection).  Parts 1 and 2: three-level hierarchies only.
+void launch_blocked_prefix(hipStream_t stream, const double* in, const slamk::StateView& view, const slamk::UpperLevels& u, int part = 0)
 {
     const int L = u.L;
     if (L >= 3 && L <= 8 && u.n[1] <= 65536)
     {
         // the small upper levels in one launch (3 launches for 100k particles instead of 5)
-        hipLaunchKernelGGL(slamk::k_scan_chunks, dim3((unsigned)cdiv(cdiv(u.n[0], 64), 4)), dim3(256), 0, stream, in, view, u.n[0],
-                           u.s[0], u.tot[0]);
+        if (part != 2)
+            hipLaunchKernelGGL(slamk::k_scan_chunks, dim3((unsigned)cdiv(cdiv(u.n[0], 64), 4)), dim3(256), 0, stream, in, view, u.n[0],
+                               u.s[0], u.tot[0]);
+        if (part == 1) return;
         hipLaunchKernelGGL(slamk::k_scan_upper, dim3(1), dim3(1024), 0, stream, u);
         hipLaunchKernelGGL(slamk::k_downsweep, dim3((unsigned)cdiv(u.n[0], 256)), dim3(256), 0, stream, u.s[0], u.P[1], u.n[0],
                            u.P[0]);
@@ -923,7 +937,34 @@ void launch_blocked_prefix(hipStream_t stream, const double* in, const slamk::St
 }
 
 // running sums of the weights of all shards (n_glob entries) into lvl_P[0], in the configured order
-int do_prefix(slam_mcl* h, const slamk::StateView& view)
+bool select_fusable(const slam_mcl* h)
+{
+    return tuning().select_fuse != 0 && h->prm.prefix_order == SLAM_PREFIX_BLOCKED && h->lvl_n.size() == 3 &&
+           h->lvl_n[1] <= slamk::SELECT_FUSED_MAX_N1;
+}
+slamk::UpperLevels upper_levels(const slam_mcl* h)
+{
+    slamk::UpperLevels u;
+    u.L = (int)h->lvl_n.size();
+    for (int l = 0; l < u.L; ++l)
+    {
+        u.n[l] = h->lvl_n[l];
+        u.s[l] = h->lvl_s[l];
+        u.tot[l] = h->lvl_tot[l];
+        u.P[l] = h->lvl_P[l];
+    }
+    return u;
+}
+// lvl_P[0] in full after a selection that did without it (readers of the running sums: tests, tools, device_state)
+int complete_prefix(slam_mcl* h)
+{
+    if (!h->prefix_partial) return SLAM_OK;
+    launch_blocked_prefix(h->stream, nullptr, slamk::StateView{}, upper_levels(h), 2);
+    HIPCHK(hipGetLastError());
+    h->prefix_partial = false;
+    return SLAM_OK;
+}
+int do_prefix(slam_mcl* h, const slamk::StateView& view, bool for_fused_select = false)
 {
     const double* lin = nullptr;  // SLAM_WEIGHT_LOG: the selection runs on exp(lw - max lw)
     if (h->prm.weight_domain == SLAM_WEIGHT_LOG)
@@ -953,16 +994,8 @@ int do_prefix(slam_mcl* h, const slamk::StateView& view)
         HIPCHK(hipGetLastError());
         return SLAM_OK;
     }
-    slamk::UpperLevels u;
-    u.L = (int)h->lvl_n.size();
-    for (int l = 0; l < u.L; ++l)
-    {
-        u.n[l] = h->lvl_n[l];
-        u.s[l] = h->lvl_s[l];
-        u.tot[l] = h->lvl_tot[l];
-        u.P[l] = h->lvl_P[l];
-    }
-    launch_blocked_prefix(h->stream, lin, view, u);
+    launch_blocked_prefix(h->stream, lin, view, upper_levels(h), for_fused_select ? 1 : 0);
+    h->prefix_partial = for_fused_select;
     HIPCHK(hipGetLastError());
     return SLAM_OK;
 }
@@ -996,9 +1029,14 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
     view.wbase = gathered ? gathered_w : nullptr;
     {
         slam_mcl::Span span(h, G_RESAMPLE);
-        int rc = do_prefix(h, view);
+        const bool fused = select_fusable(h);
+        h->prefix_partial = false;
+        int rc = do_prefix(h, view, fused);
         if (rc) return rc;
         slamk::SelectArgs s;
+        s.s0 = h->lvl_s[0];
+        s.tot0 = h->lvl_tot[0];
+        s.n1 = (int)(h->lvl_n.size() > 1 ? h->lvl_n[1] : 0);
         s.P = h->lvl_P[0];
         s.n_total = h->n_glob;
         s.slot_first = h->prm.global_first;
@@ -1011,7 +1049,10 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
         s.view = view;
         s.keys = h->prm.sort == SLAM_SORT_FULL ? h->keys : nullptr;
         s.slots = h->slots;
-        hipLaunchKernelGGL(slamk::k_select, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, s);
+        if (fused)
+            hipLaunchKernelGGL(slamk::k_select<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, s);
+        else
+            hipLaunchKernelGGL(slamk::k_select<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, s);
         HIPCHK(hipGetLastError());
     }
     if (h->surv_list && n_shards == 1 && clone_local)
@@ -1038,14 +1079,17 @@ int do_resample(slam_mcl* h, const double* gathered, int n_shards, bool clone_lo
         if (rc) return rc;
     }
     const int32_t* perm = nullptr;
+    bool states_moved = false;
     if (h->prm.sort == SLAM_SORT_FULL)
     {
         slam_mcl::Span span(h, G_SORT);
         // (weight descending, slot ascending): any stable sort gives this order
-        int rc = sort_by_weight(h, n);
+        const slamk::GatherEpilogue ge = {view, h->idx, n, h->state2, h->src};
+        int rc = sort_by_weight(h, n, &ge, &states_moved);
         if (rc) return rc;
         perm = h->perm;
     }
+    if (!states_moved)
     {
         slam_mcl::Span span(h, G_RESAMPLE);
         hipLaunchKernelGGL(slamk::k_gather, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, h->stream, view, h->idx, perm, n,
@@ -1905,6 +1949,7 @@ SLAM_API int slam_mcl_get_prefix(slam_mcl* h, double* prefix, double* sum)
 {
     int rc = check_handle(h);
     if (rc) return rc;
+    if ((rc = complete_prefix(h))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (prefix) HIPCHK(hipMemcpy(prefix, h->lvl_P[0], sizeof(double) * h->n_glob, hipMemcpyDeviceToHost));
     if (sum) HIPCHK(hipMemcpy(sum, h->lvl_P[0] + (h->n_glob - 1), sizeof(double), hipMemcpyDeviceToHost));
@@ -2081,6 +2126,7 @@ SLAM_API int slam_mcl_synchronize(slam_mcl* h)
 SLAM_API int slam_mcl_device_state_get(slam_mcl* h, slam_mcl_device_state* out)
 {
     if (!h || !out) return fail(SLAM_ERR_ARG, "null");
+    if (int rc = complete_prefix(h)) return rc;  // (enqueued on the handle's stream, like everything that writes these arrays)
     out->state_dev = h->state;
     out->prefix_dev = h->lvl_P[0];
     out->n_particles = h->n;
@@ -2429,6 +2475,8 @@ SLAM_API int slam_resample_select_static(int32_t device, void* stream, const dou
     // (every scratch entry that is read has been written by this call: nothing needs clearing)
     launch_blocked_prefix(st, weights_dev, none, u);
     slamk::SelectArgs s;
+    s.s0 = s.tot0 = nullptr;
+    s.n1 = 0;
     s.P = u.P[0];
     s.n_total = n;
     s.slot_first = 0;
@@ -2441,7 +2489,7 @@ SLAM_API int slam_resample_select_static(int32_t device, void* stream, const dou
     s.view = none;
     s.keys = nullptr;
     s.slots = nullptr;
-    hipLaunchKernelGGL(slamk::k_select, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, s);
+    hipLaunchKernelGGL(slamk::k_select<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, s);
     HIPCHK(hipGetLastError());
     return SLAM_OK;
 }

@@ -332,8 +332,17 @@ __device__ __forceinline__ int rank_in_bucket(const uint64_t* k, const int32_t* 
 // everything but the comparisons: 64-bit integer compares and the mask logic of the composite order are what is left).
 constexpr int GROUP = 1;
 constexpr int GROUP_CAP = 2048;  // elements of one group ranked in LDS (24 KB)
-template <typename V>
-__global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V* out_vals, int lds_cap /* <= GROUP_CAP */)
+// epi(position, value): whatever the caller wants done with every pair as it reaches its final position (the filter
+// gathers the particle states there: one launch fewer per step).
+struct NoEpilogue
+{
+    template <typename V>
+    __device__ __forceinline__ void operator()(int, V) const
+    {
+    }
+};
+template <typename V, typename EPI>
+__global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V* out_vals, int lds_cap /* <= GROUP_CAP */, EPI epi)
 {
     __shared__ uint64_t sk[GROUP_CAP];
     __shared__ int32_t sp[GROUP_CAP];
@@ -367,7 +376,9 @@ __global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V*
             const uint64_t k = sk[e];
             const int32_t p = sp[e];
             r = rank_in_bucket(sk, sp, lo, hi, e, k, p);
-            out_vals[first + lo + r] = vals[p];
+            const V v = vals[p];
+            out_vals[first + lo + r] = v;
+            epi(first + lo + r, v);
         }
         else
         {
@@ -375,15 +386,18 @@ __global__ void __launch_bounds__(256) k_ss_buckets(const V* vals, Scratch s, V*
             const uint64_t k = s.key2[first + e];
             const int32_t p = s.pos2[first + e];
             r = rank_in_bucket(s.key2 + first, s.pos2 + first, lo, hi, e, k, p);
-            out_vals[first + lo + r] = vals[p];
+            const V v = vals[p];
+            out_vals[first + lo + r] = v;
+            epi(first + lo + r, v);
         }
     }
 }
 
 // Enqueues the sort on `stream`.  scratch: scratch_bytes(n) bytes, 256-byte aligned.  coarse: steps 1-4 only.
-template <typename K, typename V>
+template <typename K, typename V, typename EPI = NoEpilogue>
 __host__ inline void sort_pairs(void* scratch, const K* keys, const V* vals, V* out_vals, int64_t n, bool coarse, hipStream_t stream,
-                                int lds_cap = GROUP_CAP /* tests: a smaller value sends groups of buckets to the ranking from memory */)
+                                int lds_cap = GROUP_CAP /* tests: a smaller value sends groups of buckets to the ranking from memory */,
+                                EPI epi = EPI() /* full sorts only */)
 {
     const Scratch s = carve(scratch, n);
     const int nblocks = (int)((n + ITEMS - 1) / ITEMS);
@@ -395,8 +409,8 @@ __host__ inline void sort_pairs(void* scratch, const K* keys, const V* vals, V* 
     else
     {
         hipLaunchKernelGGL((k_ss_scatter<K, V, false>), dim3(nblocks), dim3(256), 0, stream, keys, vals, (int)n, nblocks, s, out_vals);
-        hipLaunchKernelGGL((k_ss_buckets<V>), dim3(BUCKETS / GROUP), dim3(256), 0, stream, vals, s, out_vals,
-                           lds_cap < GROUP_CAP ? lds_cap : GROUP_CAP);
+        hipLaunchKernelGGL((k_ss_buckets<V, EPI>), dim3(BUCKETS / GROUP), dim3(256), 0, stream, vals, s, out_vals,
+                           lds_cap < GROUP_CAP ? lds_cap : GROUP_CAP, epi);
     }
 }
 
