@@ -13,7 +13,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"k_rays_pl": "k_rays_plILi5ELb0ELb0EE", "k_sum_lw": "k_sum_lw", "k_weights_L<0>": "k_weights_LILi0EE",
-           "k_weights_S2<tiled>": "k_weights_S2ILb1ELb0EE"}
+           "k_weights_S2<tiled>": "k_weights_S2ILb1ELb0ELb0EE", "k_weights_S2F": "k_weights_S2FE"}
 
 
 def count(lines, key):

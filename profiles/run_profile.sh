@@ -3,7 +3,7 @@
 #   kernel-trace + stats, then PMC passes in runs of their own (never combined with tracing).
 # Usage: bash profiles/run_profile.sh <tag>      -> gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -20,4 +20,11 @@ timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o bench -- $
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" -o bench -- $BENCH > "$OUT/pmc_l2.log" 2>&1 || exit 3
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD -d "$OUT/pmc_sq" -o bench -- $BENCH > "$OUT/pmc_sq.log" 2>&1 || exit 4
 timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d "$OUT/pmc_grbm" -o bench -- $BENCH > "$OUT/pmc_grbm.log" 2>&1 || exit 5
-ls -R "$OUT" | head -60
+# summaries on the box (the databases of the counter passes exceed what gpurun copies back), then the databases go
+cd "$REPO" && python3 profiles/summarize.py "$TAG" > "$OUT/summary.log" 2>&1 || { tail -20 "$OUT/summary.log"; exit 6; }
+mkdir -p "$REPO/gpurun_out/prof_${TAG}_out"
+cp profiles/rocprof_${TAG}*.txt profiles/pmc_weights_kernel.json "$REPO/gpurun_out/prof_${TAG}_out/"
+grep '^{' "$OUT/trace.log" > "$REPO/gpurun_out/prof_${TAG}_out/bench_line_trace_pass1.json" || true
+grep '^{' "$OUT/trace_sec.log" > "$REPO/gpurun_out/prof_${TAG}_out/bench_line_trace_pass2.json" || true
+rm -rf "$OUT"/trace "$OUT"/trace_sec "$OUT"/pmc_fetch "$OUT"/pmc_l2 "$OUT"/pmc_sq "$OUT"/pmc_grbm
+ls -l "$REPO/gpurun_out/prof_${TAG}_out"

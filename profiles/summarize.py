@@ -17,10 +17,10 @@ def kernel_stats(db):
     return "\n".join(out)
 
 
-def timed_region(db, steps=20, after=20):
+def timed_region(db, steps=20, after=23):
     """What bench.py's timed region holds: per kernel the average over the `steps` launches per step-kernel that come
-    before the last `after` steps (bench.py runs the timed steps, then `after` more with every group bracketed by
-    events; rocprofv3's own averages also include the warm-up steps, whose wide cloud makes them slower), and the
+    before the last `after` steps (bench.py runs the timed steps, then 20 more with every group bracketed by events and 3
+    for the host's own cost; rocprofv3's own averages also include the warm-up steps, whose wide cloud makes them slower), and the
     weighting pass as one span, from the start of k_order_keys to the end of k_sum_lw."""
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, start, end from kernels order by start").fetchall()
@@ -60,30 +60,32 @@ def slam_summary(base, tag):
         cur = sqlite3.connect(t[0]).cursor()
         big = cur.execute("select max(grid_x) from kernels where name like '%k_weights_S2%'").fetchone()[0]
         w = cur.execute("select min(start), max(end), count(*) from kernels where name like '%k_weights_S2%' and grid_x=?", (big,)).fetchone()
-        lines.append(f"\n## kernel trace: the {w[2]} launches of k_weights_S2 with grid {big} threads and the tile kernels around them")
+        lines.append(f"\n## kernel trace: the {w[2]} launches of k_weights_S2* with grid {big} threads and the tile kernels around them")
         lines.append("%-84s %8s %12s %12s %12s" % ("kernel", "launches", "avg_ns", "min_ns", "max_ns"))
         rows = cur.execute("select name, count(*), avg(end-start), min(end-start), max(end-start) from kernels where start>=? and end<=? "
-                           "and (name like '%k_weights_S2%' or name like '%k_tile_%' or name like '%k_tab_gather%' or name like '%k_set_sectors%') "
+                           "and (name like '%k_weights_S2%' or name like '%k_tile_%' or name like '%k_tab_gather%' or name like '%k_set_sectors%' "
+                           "or name like '%k_defer_split%' or name like '%k_mark_sources%' or name like '%k_list_sources%') "
                            "and (name not like '%k_weights_S2%' or grid_x=?) group by name order by 3 desc", (w[0] - 40_000_000, w[1] + 5_000_000, big)).fetchall()
         for n, c, a, mn, mx in rows:
             lines.append("%-84s %8d %12.0f %12d %12d" % (n[:84], c, a, mn, mx))
-    lines.append("\n## counters of k_weights_S2<true> per launch (largest grid only), separate passes")
-    waves = None
+    lines.append("\n## counters of the grid-SLAM kernels per launch, by kernel (every launch has the grid of 125 000 wavefronts; the replay and")
+    lines.append("## the edge pass of k_weights_S2<true, false, false> leave most of them at once), separate passes")
     vals = {}
     for sub in ("pmc_sq", "pmc_fetch", "pmc_l2", "pmc_grbm"):
         for d in glob.glob(os.path.join(base, sub, "*_results.db")):
             cur = sqlite3.connect(d).cursor()
-            big = cur.execute("select max(grid_size) from counters_collection where kernel_name like '%k_weights_S2%'").fetchone()[0]
-            for c, n, a in cur.execute("select counter_name, count(*), avg(value) from counters_collection where kernel_name like '%k_weights_S2%' "
-                                       "and grid_size=? group by counter_name order by counter_name", (big,)).fetchall():
-                lines.append("%-28s launches %4d  avg per launch %18.1f" % (c, n, a))
-                vals[c] = a
+            for kn, c, n, a, mx in cur.execute("select kernel_name, counter_name, count(*), avg(value), max(value) from counters_collection "
+                                               "where kernel_name like '%k_weights_S2%' group by kernel_name, counter_name order by kernel_name, counter_name").fetchall():
+                short = kn.split("(")[0].replace("void slamk::", "").replace("slamk::", "")
+                lines.append("%-40s %-20s launches %4d  avg per launch %18.1f  max %18.1f" % (short, c, n, a, mx))
+                if "k_weights_S2F" in kn:
+                    vals[c] = a
     if "SQ_WAVES" in vals and "SQ_INSTS_VALU" in vals:
         rays = vals["SQ_WAVES"] * 90.0
-        lines.append("   -> %.0f VALU and %.0f SALU wavefront instructions per ray (%.2f M rays per launch); round 1's k_weights_S_wave: 870 VALU"
+        lines.append("   -> k_weights_S2F: %.0f VALU and %.0f SALU wavefront instructions per ray (%.2f M rays per launch); round 2's k_weights_S2<tiled>: 392 + 398"
                      % (vals["SQ_INSTS_VALU"] / rays, vals.get("SQ_INSTS_SALU", 0.0) / rays, rays / 1e6))
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-        lines.append("   -> HBM traffic per launch: %.2f GB read (FETCH_SIZE KB doubled for gfx950) + %.2f GB written"
+        lines.append("   -> k_weights_S2F: HBM traffic per launch %.2f GB read (FETCH_SIZE KB doubled for gfx950) + %.2f GB written"
                      % (2 * vals["FETCH_SIZE"] * 1024 / 1e9, vals["WRITE_SIZE"] * 1024 / 1e9))
     text = "\n".join(lines) + "\n"
     open(os.path.join("profiles", f"rocprof_{tag}_slam.txt"), "w").write(text)
@@ -135,11 +137,25 @@ def weights_traffic(base):
         out["kernels"][k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes": b}
         total += b
     out["hbm_bytes_per_launch"] = total
-    # the grid-SLAM walk kernel of the secondary entry (not part of the headline figure)
-    fk, wk = avg(f[0], "FETCH_SIZE", "%k_weights_S2%"), avg(w[0], "WRITE_SIZE", "%k_weights_S2%")
-    if fk is not None and wk is not None:
-        out["kernels"]["k_weights_S2 (125 000-particle shard)"] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
-                                                                   "hbm_bytes": 2.0 * fk * 1024.0 + wk * 1024.0}
+    # the grid-SLAM kernels of the secondary entry (not part of the headline figure).  Since round 3 an update weighs the
+    # particles with k_weights_S2F and leaves the canvases to the resample, which runs the ordinary kernel
+    # k_weights_S2<true, false, false> on the selected particles (the "replay"; one more launch of it per update serves the
+    # particles too close to row 0 / column 0, usually none).  Per deferred update: the mean over the k_weights_S2F launches,
+    # and the sum over the other kernel's launches without its full passes (the first update or two of a filter run it on
+    # every particle: values above 30 % of the largest), divided by the number of k_weights_S2F launches.
+    def per_update(db, counter):
+        cur = sqlite3.connect(db).cursor()
+        f = [r[0] for r in cur.execute("select value from counters_collection where counter_name=? and kernel_name like '%k_weights_S2F%'", (counter,))]
+        o = [r[0] for r in cur.execute("select value from counters_collection where counter_name=? and kernel_name like '%k_weights_S2<true, false, false>%'", (counter,))]
+        if not f:
+            return None, None
+        part = [v for v in o if v <= 0.3 * max(o)] if o else []
+        return sum(f) / len(f), sum(part) / len(f)
+    (ff, fr), (wf, wr) = per_update(f[0], "FETCH_SIZE"), per_update(w[0], "WRITE_SIZE")
+    if ff is not None and wf is not None:
+        out["kernels"]["k_weights_S2F (125 000-particle shard)"] = {"FETCH_SIZE_KB": ff, "WRITE_SIZE_KB": wf, "hbm_bytes": 2.0 * ff * 1024.0 + wf * 1024.0}
+        out["kernels"]["k_weights_S2 on the survivors (125 000-particle shard, per deferred update)"] = {
+            "FETCH_SIZE_KB": fr, "WRITE_SIZE_KB": wr, "hbm_bytes": 2.0 * fr * 1024.0 + wr * 1024.0}
     # the weighting kernel of the 16384^2 shard (12.5 M particles; its sparse cloud gets the wave-per-particle kernel
     # k_weights_L<0> from the second pass on): the launches with the largest grid
     def avg_big(db, counter, like):
@@ -165,12 +181,20 @@ def weights_traffic(base):
                 big = cur.execute("select max(grid_size) from counters_collection where kernel_name like ?", (like,)).fetchone()[0]
                 cond, args = cond + " and grid_size=?", args + [big]
             return {c: float(a) for c, a in cur.execute(f"select counter_name, avg(value) from counters_collection where {cond} group by counter_name", args)}
+        SQ_KEYS = ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")
         for name, like, big in (("k_rays_pl", "%k_rays_pl<5, false, false>%", False), ("k_sum_lw", "%k_sum_lw%", False),
-                                ("k_weights_S2 (125 000-particle shard)", "%k_weights_S2%", True),
                                 ("weighting kernel of the 16384^2 shard (k_weights_L<0>, 12.5 M particles)", "%k_weights_L<0>%", True)):
             v = sq_of(like, big)
             if v and name in out["kernels"]:
-                out["kernels"][name]["sq"] = {k: v[k] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES") if k in v}
+                out["kernels"][name]["sq"] = {k: v[k] for k in SQ_KEYS if k in v}
+        nf, nr = "k_weights_S2F (125 000-particle shard)", "k_weights_S2 on the survivors (125 000-particle shard, per deferred update)"
+        if nf in out["kernels"]:
+            sf, sr = {}, {}
+            for k in SQ_KEYS:
+                a, b = per_update(sq[0], k)
+                if a is not None:
+                    sf[k], sr[k] = a, b
+            out["kernels"][nf]["sq"], out["kernels"][nr]["sq"] = sf, sr
     # bench.py quotes hbm_bytes_per_launch only while the kernel sources are the ones measured here
     import hashlib
     h = hashlib.sha256()
@@ -191,7 +215,7 @@ def main(tag):
         try:
             lines.append(kernel_stats(d) if name.startswith("trace") else pmc_stats(d))
             if name == "trace":
-                lines.append("\n## timed region of the trace run (bench.py defaults: 5 warm-up + 20 timed steps, then 20 steps bracketed by events)")
+                lines.append("\n## timed region of the trace run (bench.py defaults: 5 warm-up + 20 timed steps, then 20 steps bracketed by events and 3 more)")
                 lines.append(timed_region(d))
         except Exception as e:  # noqa: BLE001
             lines.append(f"(could not read: {e})")

@@ -824,9 +824,16 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2F(WeightArgs a, Tile
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int first_n = max_iter < 64 ? max_iter : 64;  // samples of the ordered first pass
-    double acc = 0.0;
-    for (int b0 = 0; b0 < a.B; b0 += 64)
+    // What a batch of 64 beams leaves behind once its ordered first pass is over: the hits found there (mine), and for the
+    // rays still searching (go) their position, step and cell at sample 64.
+    struct Head
     {
+        bool go;
+        double x, y, dx, dy;
+        int pi, pj;
+        slam_ray_result mine;
+    };
+    auto head = [&](int b0) -> Head {
         const int b = b0 + lane;
         const int cnt = (a.B - b0) < 64 ? (a.B - b0) : 64;
         double dx = 0.0, dy = 0.0, z2 = 0.0;
@@ -980,56 +987,111 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2F(WeightArgs a, Tile
                 slam_cell_of(a.rows, hx, hy, &hi, &hj);
                 mine.hcell = hi * a.cols + hj;
             }
-            bool go = b < a.B && my_khit == 0 && !my_ended && max_iter > 64;
-            double x = x64, y = y64;
-            int pi = ci64, pj = cj64;
-            for (int k0 = 64; __ballot(go) != 0; k0 += S2F_U)
+        }
+        Head h;
+        h.go = !literal && b < a.B && my_khit == 0 && !my_ended && max_iter > 64;
+        h.x = x64;
+        h.y = y64;
+        h.dx = dx;
+        h.dy = dy;
+        h.pi = ci64;
+        h.pj = cj64;
+        h.mine = mine;
+        return h;
+    };
+    // The search of up to 64 rays from sample 65 on, lane = ray, eight samples' cells in flight (see above).
+    // (The end of the beam, slam/raycast.cpp:216, is tested only from sample k_safe = floor(max_dist) - 1 on: a sample k is
+    // k steps of length 1 +- 1e-15 from the sensor, a cell of margin; the localization kernels' k_safe, ray.h.)
+    auto far_walk = [&](bool go, double x, double y, const double dx, const double dy, int pi, int pj, slam_ray_result& res) {
+        int k0 = 64;
+        for (; k0 + S2F_U <= a.k_safe && k0 + S2F_U <= max_iter && __ballot(go) != 0; k0 += S2F_U)
+        {
+            double xs[S2F_U], ys[S2F_U];
+            int is[S2F_U], js[S2F_U];
+            uint8_t cv[S2F_U];
+#pragma unroll
+            for (int u = 0; u < S2F_U; ++u)
             {
-                double xs[S2F_U], ys[S2F_U];
-                int is[S2F_U], js[S2F_U];
-                uint8_t cv[S2F_U];
+                x += dx;
+                y += dy;
+                xs[u] = x;
+                ys[u] = y;
+                is[u] = slam_f2i((rows_d - y) - 1.0);
+                js[u] = slam_f2i(x);
+                const bool ok = go && slam_in_bounds(a.rows, a.cols, is[u], js[u]);
+                cv[u] = *fmap.cell_ptr(fmap.entry(ok, is[u], js[u]), ok ? is[u] : 0, ok ? js[u] : 0);
+            }
 #pragma unroll
-                for (int u = 0; u < S2F_U; ++u)
+            for (int u = 0; u < S2F_U; ++u)
+            {
+                if (go && (is[u] != pi || js[u] != pj))
                 {
-                    x += dx;
-                    y += dy;
-                    xs[u] = x;
-                    ys[u] = y;
-                    is[u] = slam_f2i((rows_d - y) - 1.0);
-                    js[u] = slam_f2i(x);
-                    const bool ok = go && k0 + u + 1 <= max_iter && slam_in_bounds(a.rows, a.cols, is[u], js[u]);
-                    cv[u] = *fmap.cell_ptr(fmap.entry(ok, is[u], js[u]), ok ? is[u] : 0, ok ? js[u] : 0);
-                }
-#pragma unroll
-                for (int u = 0; u < S2F_U; ++u)
-                {
-                    if (go)
+                    if (!slam_in_bounds(a.rows, a.cols, is[u], js[u]))
+                        go = false;  // :176
+                    else if (cv[u] < 128)
+                    {  // :183-189
+                        res.hx = xs[u];
+                        res.hy = ys[u];
+                        res.hcell = is[u] * a.cols + js[u];
+                        go = false;
+                    }
+                    else
                     {
-                        if (k0 + u + 1 > max_iter)
-                            go = false;  // slam/raycast.cpp:163 with the sample bound of the walk
-                        else if (is[u] != pi || js[u] != pj)
+                        pi = is[u];
+                        pj = js[u];
+                    }
+                }
+            }
+        }
+        for (; __ballot(go) != 0; k0 += S2F_U)
+        {
+            double xs[S2F_U], ys[S2F_U];
+            int is[S2F_U], js[S2F_U];
+            uint8_t cv[S2F_U];
+#pragma unroll
+            for (int u = 0; u < S2F_U; ++u)
+            {
+                x += dx;
+                y += dy;
+                xs[u] = x;
+                ys[u] = y;
+                is[u] = slam_f2i((rows_d - y) - 1.0);
+                js[u] = slam_f2i(x);
+                const bool ok = go && k0 + u + 1 <= max_iter && slam_in_bounds(a.rows, a.cols, is[u], js[u]);
+                cv[u] = *fmap.cell_ptr(fmap.entry(ok, is[u], js[u]), ok ? is[u] : 0, ok ? js[u] : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < S2F_U; ++u)
+            {
+                if (go)
+                {
+                    if (k0 + u + 1 > max_iter)
+                        go = false;  // slam/raycast.cpp:163 with the sample bound of the walk
+                    else if (is[u] != pi || js[u] != pj)
+                    {
+                        if (!slam_in_bounds(a.rows, a.cols, is[u], js[u]))
+                            go = false;  // :176
+                        else if (cv[u] < 128)
+                        {  // :183-189
+                            res.hx = xs[u];
+                            res.hy = ys[u];
+                            res.hcell = is[u] * a.cols + js[u];
+                            go = false;
+                        }
+                        else
                         {
-                            if (!slam_in_bounds(a.rows, a.cols, is[u], js[u]))
-                                go = false;  // :176
-                            else if (cv[u] < 128)
-                            {  // :183-189
-                                mine.hx = xs[u];
-                                mine.hy = ys[u];
-                                mine.hcell = is[u] * a.cols + js[u];
-                                go = false;
-                            }
-                            else
-                            {
-                                const double ex = xs[u] - sx, ey = ys[u] - sy;
-                                if (ex * ex + ey * ey >= a.zmax2) go = false;  // :216
-                                pi = is[u];
-                                pj = js[u];
-                            }
+                            const double ex = xs[u] - sx, ey = ys[u] - sy;
+                            if (ex * ex + ey * ey >= a.zmax2) go = false;  // :216
+                            pi = is[u];
+                            pj = js[u];
                         }
                     }
                 }
             }
         }
+    };
+    auto weigh = [&](int b0, const slam_ray_result& mine) -> double {
+        const int b = b0 + lane;
         double lw = 0.0;
         if (b < a.B)
         {
@@ -1042,7 +1104,103 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2F(WeightArgs a, Tile
                 a.hit_cell[o] = mine.hcell;
             }
         }
-        for (int l = 0; l < cnt; ++l) acc += readlane_f64(lw, l);
+        return lw;
+    };
+    // Two batches at a time.  The searches are independent of everything (nothing is written), so those of the second
+    // batch need not wait for the first batch's: its searching rays move into the lanes whose own ray of the first batch has
+    // ended already (about half of them: walls nearer than 64 cells), and ONE loop serves both batches; its length is the
+    // longest ray's, where two loops cost the longest ray of each batch (90 beams: 64 + 26, the second loop ran 26 lanes).
+    double acc = 0.0;
+    for (int b0 = 0; b0 < a.B; b0 += 128)
+    {
+        Head h0 = head(b0);
+        const bool two = b0 + 64 < a.B;
+        Head h1;
+        h1.go = false;
+        h1.x = h1.y = h1.dx = h1.dy = 0.0;
+        h1.pi = h1.pj = 0;
+        h1.mine.hx = h1.mine.hy = -1.0;
+        h1.mine.hcell = -1;
+        if (two) h1 = head(b0 + 64);
+        const uint64_t G0 = __ballot(h0.go), G1 = __ballot(h1.go);
+        const uint64_t lower = s2_below(lane);
+        const int rank1 = __builtin_popcountll(G1 & lower);
+        int moved = 0, src = lane;
+        bool took = false;
+        double wx = h0.x, wy = h0.y, wdx = h0.dx, wdy = h0.dy;
+        int wpi = h0.pi, wpj = h0.pj;
+        if (G1)
+        {
+            const uint64_t F = ~G0;
+            const int nfree = __builtin_popcountll(F), n1 = __builtin_popcountll(G1);
+            moved = nfree < n1 ? nfree : n1;
+            int* src_of = reinterpret_cast<int*>(bits);  // (the geometry bits have served: both first passes are over)
+            if (h1.go) src_of[rank1] = lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int rf = __builtin_popcountll(F & lower);
+            took = !h0.go && rf < moved;
+            if (took) src = src_of[rf];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const double tx = __shfl(h1.x, src), ty = __shfl(h1.y, src), tdx = __shfl(h1.dx, src), tdy = __shfl(h1.dy, src);
+            const int tpi = __shfl(h1.pi, src), tpj = __shfl(h1.pj, src);
+            if (took)
+            {
+                wx = tx;
+                wy = ty;
+                wdx = tdx;
+                wdy = tdy;
+                wpi = tpi;
+                wpj = tpj;
+            }
+        }
+        slam_ray_result res = {-1.0, -1.0, -1};
+        far_walk(h0.go || took, wx, wy, wdx, wdy, wpi, wpj, res);
+        if (h0.go) h0.mine = res;
+        if (G1)
+        {
+            // results of the rays that moved go back to their beams' lanes: {hx or +inf for "no hit", hy} (16 bytes per ray)
+            double* slot = reinterpret_cast<double*>(bits);
+            if (took)
+            {
+                slot[2 * src] = res.hcell >= 0 ? res.hx : __builtin_inf();
+                slot[2 * src + 1] = res.hy;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (h1.go && rank1 < moved)
+            {
+                const double hx = slot[2 * lane], hy = slot[2 * lane + 1];
+                if (hx != __builtin_inf())
+                {
+                    h1.mine.hx = hx;
+                    h1.mine.hy = hy;
+                    int hi, hj;
+                    slam_cell_of(a.rows, hx, hy, &hi, &hj);
+                    h1.mine.hcell = hi * a.cols + hj;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // (more searching rays in the second batch than free lanes: the rest in a loop of their own)
+            const bool left = h1.go && rank1 >= moved;
+            if (__ballot(left) != 0)
+            {
+                slam_ray_result r2 = {-1.0, -1.0, -1};
+                far_walk(left, h1.x, h1.y, h1.dx, h1.dy, h1.pi, h1.pj, r2);
+                if (left) h1.mine = r2;
+            }
+        }
+        const double lw0 = weigh(b0, h0.mine);
+        const int cnt0 = (a.B - b0) < 64 ? (a.B - b0) : 64;
+        for (int l = 0; l < cnt0; ++l) acc += readlane_f64(lw0, l);
+        if (two)
+        {
+            const double lw1 = weigh(b0 + 64, h1.mine);
+            const int cnt1 = (a.B - b0 - 64) < 64 ? (a.B - b0 - 64) : 64;
+            for (int l = 0; l < cnt1; ++l) acc += readlane_f64(lw1, l);
+        }
     }
     if (lane == 0) a.w[p] = a.log_domain ? acc : dm_exp(acc);
 }
