@@ -770,10 +770,56 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2(WeightArgs a, TileA
 // (The loop of :163 can end earlier only once a hit has been found, and the free / occupied updates are the canvas's
 // business, which the second half of the deferred update settles for the survivors.)  The geometry phase shrinks to
 // one pass as well.  Same hits, same weights, bit for bit, as k_weights_S2<true, false, true>.
-// Measured (125 000 x 90): that kernel 16.7 ms, this one 11.8 ms.  Tried and dropped: ordering only the first
-// kstar samples (the search grows: +1.2 ms); searching with lane = sample over the geometry bits of all passes, one ray or
-// four side by side (fewer vector instructions, 38 000 against 41 000 per particle, but 26 000 scalar ones: 13.2 ms).
-enum { S2F_U = 8 };
+// Measured (125 000 x 90): that kernel 16.7 ms; this one 11.8 ms at first, 8.1 ms with the searches of two batches
+// merged and the end-of-beam test left to the last samples.  Tried and dropped: ordering only the first kstar samples, with
+// a routine of its own that knows nothing but the LDS window (the search grows by 41 samples per ray: step +1.2 ms at first,
+// +1.9 ms against the merged loop: lane = sample costs 4 instructions per sample, the search 30 at the occupancy of its
+// lanes); searching with lane = sample over the geometry bits of all passes, one ray or four side by side (fewer vector
+// instructions, 38 000 against 41 000 per particle, but 26 000 scalar ones: 13.2 ms).
+// The ordered first pass of one ray in k_weights_S2F (samples 1 .. 64, m = their geometry bits): s2_ray's general case
+// for a first pass (found = drew = false on entry) on a TiledDefer map, and nothing else of s2_ray.
+__device__ __forceinline__ int s2f_first(const TiledDefer& map, uint4 m, int rows, int cols, int i0, int j0, int si, int sj, int k_far, int k_vfar,
+                                         bool draw_occ, const uint8_t* luts, int lane, bool* ended)
+{
+    const int Lfar = k_far - 1, Lvfar = k_vfar - 1;
+    const uint32_t r_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.x), r_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.y);
+    const uint32_t c_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.z), c_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.w);
+    const uint64_t R = ((uint64_t)r_hi << 32) | r_lo, C = ((uint64_t)c_hi << 32) | c_lo;
+    const int er = (int)__builtin_amdgcn_mbcnt_hi(r_hi, __builtin_amdgcn_mbcnt_lo(r_lo, 0)) + (__builtin_amdgcn_inverse_ballot_w64(R) ? 1 : 0);
+    const int ec = (int)__builtin_amdgcn_mbcnt_hi(c_hi, __builtin_amdgcn_mbcnt_lo(c_lo, 0)) + (__builtin_amdgcn_inverse_ballot_w64(C) ? 1 : 0);
+    const int i = __mul24(er, si) + i0, j = __mul24(ec, sj) + j0;
+    const uint64_t N = R | C;
+    const uint64_t INB = __ballot(slam_in_bounds(rows, cols, i, j));
+    const uint64_t cand = N & INB, oob = N & ~INB;
+    const bool have = __builtin_amdgcn_inverse_ballot_w64(cand);
+    const bool near = lane + 1 <= map.kstar;  // in the LDS window (may meet another ray's cells); later samples in memory
+    const int at = have && near ? map.pwi(i, j) : 0;
+    const uint8_t far_v = *map.cell_ptr(map.entry(have && !near, i, j), i, j);
+    const uint8_t cv = near ? map.pw[at] : far_v;
+    const uint64_t OCC = __ballot(cv < 128) & cand;
+    const int f_oob = s2_first(oob);                                        // break before processing (slam/raycast.cpp:176)
+    const int f_hit = s2_first(OCC);                                        // :183-189
+    const int f_far = s2_first(N & s2_from(Lfar));                          // :203-214
+    const int f_vfar = 64 <= Lvfar ? 64 : s2_first(N & s2_from(Lvfar));    // break after processing (:216)
+    const int both = f_hit > f_far ? f_hit : f_far;                         // loop condition fails after this lane (:163)
+    const int stop_incl = both < f_vfar ? both : f_vfar;
+    const int term = stop_incl < f_oob ? stop_incl : f_oob;                 // lane whose step ends the ray
+    const int lim = stop_incl < (f_oob - 1) ? stop_incl : (f_oob - 1);      // last processed lane
+    const uint64_t PROC = cand & s2_below(lim + 1);
+    const int khit = f_hit <= lim ? f_hit + 1 : 0;
+    const uint64_t WOCC = (f_far <= lim && draw_occ) ? 1ull << f_far : 0ull;
+    const uint64_t W = (PROC & s2_below(Lfar)) | WOCC;
+    *ended = term < 64;
+    // (writes beyond kstar are dropped: no ray of this scan reads those cells again)
+    const uint8_t v = luts[(__builtin_amdgcn_inverse_ballot_w64(WOCC) ? 256 : 0) + cv];
+    if (__builtin_amdgcn_inverse_ballot_w64(W) && near) map.pw[at] = v;
+    return khit;
+}
+
+#ifndef S2F_WIDE
+#define S2F_WIDE 16
+#endif
+enum { S2F_U = 8, S2F_W = S2F_WIDE };  // samples per round trip: the loop with / without the end-of-beam test
 __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2F(WeightArgs a, TileArgs ta, int win_w, int force_literal, int dk, int dw)
 {
     extern __shared__ __align__(16) unsigned char s2_lds[];
@@ -953,11 +999,10 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2F(WeightArgs a, Tile
             }
             else
             {
-                unsigned r = 0, w = 0, st = 0;
                 bool ended;
                 const bool draw_occ = bcast_f64(z2, q) != a.zmax2;  // slam/raycast.cpp:205
-                const int khit = s2_ray<false>(fmap, bits + q, a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
-                                               bcast_i32(k_vfar, q), draw_occ, first_n, luts, lane, &r, &w, &st, &ended);
+                const int khit = s2f_first(fmap, bits[q], a.rows, a.cols, i0, j0, bcast_i32(si, q), bcast_i32(sj, q), bcast_i32(k_far, q),
+                                           bcast_i32(k_vfar, q), draw_occ, luts, lane, &ended);
                 if (lane == q)
                 {
                     my_khit = khit;
@@ -1004,25 +1049,28 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2F(WeightArgs a, Tile
     // k steps of length 1 +- 1e-15 from the sensor, a cell of margin; the localization kernels' k_safe, ray.h.)
     auto far_walk = [&](bool go, double x, double y, const double dx, const double dy, int pi, int pj, slam_ray_result& res) {
         int k0 = 64;
-        for (; k0 + S2F_U <= a.k_safe && k0 + S2F_U <= max_iter && __ballot(go) != 0; k0 += S2F_U)
+        // (a hit is noted as the chunk's start position and the sample's index in the chunk, and its position formed after
+        //  the loop by the same additions: four selects per chunk instead of five per sample, no position arrays)
+        double cx = x, cy = y;
+        int hit_u = -1;
+        for (; k0 + S2F_W <= a.k_safe && k0 + S2F_W <= max_iter && __ballot(go) != 0; k0 += S2F_W)
         {
-            double xs[S2F_U], ys[S2F_U];
-            int is[S2F_U], js[S2F_U];
-            uint8_t cv[S2F_U];
+            int is[S2F_W], js[S2F_W];
+            uint8_t cv[S2F_W];
+            const double x0 = x, y0 = y;
 #pragma unroll
-            for (int u = 0; u < S2F_U; ++u)
+            for (int u = 0; u < S2F_W; ++u)
             {
                 x += dx;
                 y += dy;
-                xs[u] = x;
-                ys[u] = y;
                 is[u] = slam_f2i((rows_d - y) - 1.0);
                 js[u] = slam_f2i(x);
                 const bool ok = go && slam_in_bounds(a.rows, a.cols, is[u], js[u]);
                 cv[u] = *fmap.cell_ptr(fmap.entry(ok, is[u], js[u]), ok ? is[u] : 0, ok ? js[u] : 0);
             }
+            int hu = -1;
 #pragma unroll
-            for (int u = 0; u < S2F_U; ++u)
+            for (int u = 0; u < S2F_W; ++u)
             {
                 if (go && (is[u] != pi || js[u] != pj))
                 {
@@ -1030,9 +1078,7 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2F(WeightArgs a, Tile
                         go = false;  // :176
                     else if (cv[u] < 128)
                     {  // :183-189
-                        res.hx = xs[u];
-                        res.hy = ys[u];
-                        res.hcell = is[u] * a.cols + js[u];
+                        hu = u;
                         go = false;
                     }
                     else
@@ -1042,6 +1088,26 @@ __global__ void __launch_bounds__(64, S2_WAVES) k_weights_S2F(WeightArgs a, Tile
                     }
                 }
             }
+            if (hu >= 0)
+            {
+                cx = x0;
+                cy = y0;
+                hit_u = hu;
+            }
+        }
+        for (int t = 0; __ballot(t <= hit_u) != 0; ++t)
+            if (t <= hit_u)
+            {
+                cx += dx;
+                cy += dy;
+            }
+        if (hit_u >= 0)
+        {
+            res.hx = cx;
+            res.hy = cy;
+            int hi, hj;
+            slam_cell_of(a.rows, cx, cy, &hi, &hj);
+            res.hcell = hi * a.cols + hj;
         }
         for (; __ballot(go) != 0; k0 += S2F_U)
         {
