@@ -166,26 +166,65 @@ __device__ __forceinline__ bool slam_defer_safe(double sx, double sy, double row
 // (counts cells).  One wavefront = one particle; lane l takes beams l, l+64, ...; the per-beam
 // log-likelihoods are then added in beam order (slam/mcl.cpp:69-74) so the weight has the
 // reference's rounding.
-enum { K_WEIGHTS_L_MAX_B = 1536 };
-#define K_WEIGHTS_L_LDS(B) ((B) <= slamk::K_WEIGHTS_L_MAX_B ? (size_t)(B) * 40 : (size_t)0)
-template <int VARIANT>
-__global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
+//
+// The in-order sum.  VARIANT 0 serves wide clouds, where nearly every ray ends farther than 4 sigma from its measured
+// range and the likelihood is the clamped constant log(0 + 0.1) (slam/util.cpp:14-19).  A lane decides "certainly clamped"
+// from squared distances (slam_beam_clamped: no square root, quotient, exp or log, which in lock step all 64 lanes
+// paid whenever ONE needed them: 62 % of the groups at 1.5 % of the rays) and otherwise appends (beam, squared hit
+// distance) to a short list in LDS, in beam order.  kwl_flush evaluates the listed beams together (slam_beam_logw_d2:
+// the same statements, the same bits) and then adds, every lane the same sum: the constant for each beam between two
+// listed ones, the evaluated value for a listed one.  It runs when the list could overflow in the next group and at
+// the end, so a converged cloud (every beam listed) is as correct as a wide one (a dozen of 720).
+// Round 3: this list replaces a row of B doubles per wavefront (28.8 KB per workgroup at 720 beams: 5 wavefronts per
+// SIMD at most).  A pass over a wide cloud is bound by each wavefront's chain of dependent clearance reads: with LDS
+// padded to force 1..5 wavefronts per SIMD the 16384^2 shard took 864 / 465 / 330 / 263 / 223 ms, while removing a
+// tenth of the instructions changed nothing.  MIN_WAVES asks the compiler for the register budget of that many.
+enum { KWL_LIST = 128 };  // list entries per wavefront (at least 64: one group's worth)
+struct KwlList
 {
-    // the beams' log-likelihoods wait here for lane 0 to add them in beam order at the end (one dependent add per beam;
-    // adding them group by group took two readlanes per add as well); scans longer than the slab keep the readlane form.
-    // VARIANT 0 (round 3): on the clouds this kernel serves (wide ones) nearly every ray ends farther than 4 sigma from its
-    // measured range, where the likelihood is the clamped constant (slam/util.cpp:14-19), yet in lock step all 64 lanes
-    // paid the square root, the quotient, exp and log whenever ONE of them needed them (62 % of the groups at 1.5 % of
-    // the rays).  Now a lane decides "certainly clamped" from squared distances (slam_beam_clamped) and otherwise leaves
-    // the squared hit distance in its slot and its beam number in a list; the listed beams (a dozen of 720) are
-    // evaluated together at the end, 64 at a time, by the same statements (slam_beam_logw_d2).
-    // dynamic LDS (K_WEIGHTS_L_LDS(B) bytes, 0 beyond K_WEIGHTS_L_MAX_B beams): [4 wavefronts][B] doubles, [4][B] beam numbers
-    extern __shared__ __align__(16) unsigned char kwl_lds[];
-    const bool lw_in_lds = a.B <= K_WEIGHTS_L_MAX_B;
-    double* lw_mine = reinterpret_cast<double*>(kwl_lds) + (size_t)(threadIdx.x >> 6) * a.B;
-    unsigned short* todo = reinterpret_cast<unsigned short*>(kwl_lds + (size_t)a.B * 32) + (size_t)(threadIdx.x >> 6) * a.B;
-    const bool defer = VARIANT == 0 && lw_in_lds;
-    int n_todo = 0;  // wave-uniform
+    double val[4][KWL_LIST];
+    unsigned short beam[4][KWL_LIST];
+};
+
+// Adds the beams [b_done, upto) to acc in beam order; the n listed ones (beam numbers ascending, all in that range) hold
+// their squared hit distance (EVAL) or their final log-likelihood.  Wave-uniform control flow; every lane adds the same.
+template <bool EVAL>
+__device__ __forceinline__ double kwl_flush(const WeightArgs& a, double* val, unsigned short* beam, int n, int b_done, int upto, double acc, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the list was written by other lanes)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (EVAL && n > 0)
+    {
+        for (int k0 = 0; k0 < n; k0 += 64)
+            if (k0 + lane < n)
+            {
+                const int b = beam[k0 + lane];
+                val[k0 + lane] = slam_beam_logw_d2(val[k0 + lane], a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps, a.inv_stddev);
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int b = b_done;
+    for (int k = 0; k <= n; ++k)
+    {
+        const int nb = k < n ? __builtin_amdgcn_readfirstlane((int)beam[k < n ? k : 0]) : upto;
+        for (; b < nb; ++b) acc += a.log_eps;  // slam/mcl.cpp:69-74, a beam beyond the 4 sigma clamp
+        if (k < n)
+        {
+            acc += val[k];
+            ++b;
+        }
+    }
+    return acc;
+}
+
+template <int VARIANT, int MIN_WAVES = 1>
+__global__ void __launch_bounds__(256, MIN_WAVES) k_weights_L(WeightArgs a)
+{
+    __shared__ KwlList kwl;
+    double* val = kwl.val[threadIdx.x >> 6];
+    unsigned short* beam = kwl.beam[threadIdx.x >> 6];
+    int n_list = 0, b_done = 0;  // wave-uniform
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= a.n) return;  // whole wavefront
@@ -211,9 +250,15 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
     const unsigned off0 = (unsigned)(slam_mul24(i0, a.cols + 4) + j0 + 2 * (a.cols + 4) + 2);
     for (int b0 = 0; b0 < a.B; b0 += 64)
     {
+        if (n_list + 64 > KWL_LIST)
+        {  // the next group might not fit: add what is listed (everything before b0) now
+            acc = kwl_flush<VARIANT == 0>(a, val, beam, n_list, b_done, b0, acc, lane);
+            n_list = 0;
+            b_done = b0;
+        }
         const int b = b0 + lane;
         double lw = 0.0;
-        bool later = false;
+        bool listed = false;
         if (b < a.B)
         {
             const double theta = pth + a.angles[b] + a.srot;
@@ -226,18 +271,17 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
                 const unsigned e0 = origin_in ? a.grid[off0 + plane_off] : 0u;
                 ray_fast_L0(a.grid, plane_off, a.cols + 4, a.rows, a.cols, &PX, &PY, c, s, a.zmax2, a.k_safe,
                             a.clamp_limit ? slam_sample_limit(a.z[b], a.stddev) : SLAM_NO_SAMPLE_LIMIT, i0, j0, e0, &r, nullptr);
+                lw = slam_beam_d2(&r, sx, sy);
+                listed = !slam_beam_clamped(lw, a.z[b], a.zmax, a.clamp4);
             }
             else
+            {
                 ray_walk<false, true>(a.grid, a.rows, a.cols, sx, sy, c, s, a.z2[b], a.zmax2, nullptr, nullptr,
                                       a.max_iter, &r, &st);
-            if (defer)
-            {
-                const double d2 = slam_beam_d2(&r, sx, sy);
-                later = !slam_beam_clamped(d2, a.z[b], a.zmax, a.clamp4);
-                lw = later ? d2 : a.log_eps;
+                // (the literal kernel lists every beam with its final value: kwl_flush<false> only adds)
+                lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps, 0.0);
+                listed = true;
             }
-            else
-                lw = slam_beam_logw(&r, sx, sy, a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps, VARIANT == 0 ? a.inv_stddev : 0.0);
             if (a.hit_xy)
             {
                 const size_t o = (size_t)p * a.B + b;
@@ -246,40 +290,16 @@ __global__ void __launch_bounds__(256) k_weights_L(WeightArgs a)
                 a.hit_cell[o] = r.hcell;
             }
         }
-        if (lw_in_lds)
+        const uint64_t m = __ballot(listed);
+        if (listed)
         {
-            if (b < a.B) lw_mine[b] = lw;
-            if (defer)
-            {
-                const uint64_t m = __ballot(later);
-                if (later) todo[n_todo + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = (unsigned short)b;
-                n_todo += __builtin_popcountll(m);
-            }
+            const int k = n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            val[k] = lw;
+            beam[k] = (unsigned short)b;
         }
-        else
-        {
-            const int cnt = (a.B - b0) < 64 ? (a.B - b0) : 64;
-            for (int l = 0; l < cnt; ++l) acc += readlane_f64(lw, l);
-        }
+        n_list += __builtin_popcountll(m);
     }
-    if (lw_in_lds)
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (defer && n_todo > 0)
-        {
-            for (int k0 = 0; k0 < n_todo; k0 += 64)
-                if (k0 + lane < n_todo)
-                {
-                    const int b = todo[k0 + lane];
-                    lw_mine[b] = slam_beam_logw_d2(lw_mine[b], a.z[b], a.zmax, a.stddev, a.clamp4, a.norm, a.log_eps, a.inv_stddev);
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        if (lane == 0)
-            for (int b = 0; b < a.B; ++b) acc += lw_mine[b];  // slam/mcl.cpp:69-74
-    }
+    acc = kwl_flush<VARIANT == 0>(a, val, beam, n_list, b_done, a.B, acc, lane);
     if (lane == 0) a.w[p] = a.log_domain ? acc : dm_exp(acc);
     if (VARIANT == 1 && a.stats)
     {

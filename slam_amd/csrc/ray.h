@@ -302,6 +302,10 @@ DM_HD void slam_ray_origin(const uint8_t* Ep, unsigned plane_off, int pitch, int
 // the limit ends the search the result is (-2, -2), cell -2, which slam_beam_logw maps to the clamped value; hits
 // within the limit and rays that leave the grid are reported as always.
 #define SLAM_NO_SAMPLE_LIMIT 0x7fffffff
+// study hook (tools/slowpath_sim.cpp counts how often the re-synchronisation block of the jump loop runs): nothing in the library
+#ifndef SLAM_RAY_TRACE_RESYNC
+#define SLAM_RAY_TRACE_RESYNC(reads_so_far) ((void)0)
+#endif
 DM_HD void ray_fast_L0(const uint8_t* Ep, unsigned plane_off, int pitch, int rows, int cols, const slam_axis_pre* PX,
                        const slam_axis_pre* PY, double dx, double dy, double zmax2, int k_safe, int k_lim, int i0, int j0,
                        unsigned e0, slam_ray_result* res, unsigned* reads)
@@ -394,6 +398,7 @@ DM_HD void ray_fast_L0(const uint8_t* Ep, unsigned plane_off, int pitch, int row
                 left -= budget0;
                 if (left > 0)
                 {
+                    SLAM_RAY_TRACE_RESYNC(reads ? *reads : 0u);
                     slam_axis_real_add(&X, dx);
                     slam_axis_real_add(&Y, dy);
                     left -= 1;

@@ -893,12 +893,14 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, h->order_pass++ & 1, h->obox_host);
             h->poses_reset = false;
         }
-        hipLaunchKernelGGL(slamk::k_weights_L<0>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), K_WEIGHTS_L_LDS(B), h->stream, a);
+        // (6: the register budget of six wavefronts per SIMD, 80 VGPRs; measured on the 16384^2 shard: 95 VGPRs / 5 wavefronts
+        // 225.6 ms, 6: 204.3, 7 with 48 bytes of scratch: 215.7, 8 with 80 bytes: 220.2)
+        hipLaunchKernelGGL((slamk::k_weights_L<0, 6>), dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
     }
     else
     {
         a.grid = h->grid;
-        hipLaunchKernelGGL(slamk::k_weights_L<1>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), K_WEIGHTS_L_LDS(B), h->stream, a);
+        hipLaunchKernelGGL(slamk::k_weights_L<1>, dim3((unsigned)cdiv(h->n, 4)), dim3(256), 0, h->stream, a);
     }
     HIPCHK(hipGetLastError());
     return SLAM_OK;
