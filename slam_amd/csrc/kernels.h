@@ -183,13 +183,13 @@ enum { KWL_LIST = 128 };  // list entries per wavefront (at least 64: one group'
 struct KwlList
 {
     double val[4][KWL_LIST];
-    unsigned short beam[4][KWL_LIST];
+    int beam[4][KWL_LIST];
 };
 
 // Adds the beams [b_done, upto) to acc in beam order; the n listed ones (beam numbers ascending, all in that range) hold
 // their squared hit distance (EVAL) or their final log-likelihood.  Wave-uniform control flow; every lane adds the same.
 template <bool EVAL>
-__device__ __forceinline__ double kwl_flush(const WeightArgs& a, double* val, unsigned short* beam, int n, int b_done, int upto, double acc, int lane)
+__device__ __forceinline__ double kwl_flush(const WeightArgs& a, double* val, int* beam, int n, int b_done, int upto, double acc, int lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the list was written by other lanes)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -207,7 +207,7 @@ __device__ __forceinline__ double kwl_flush(const WeightArgs& a, double* val, un
     int b = b_done;
     for (int k = 0; k <= n; ++k)
     {
-        const int nb = k < n ? __builtin_amdgcn_readfirstlane((int)beam[k < n ? k : 0]) : upto;
+        const int nb = k < n ? __builtin_amdgcn_readfirstlane(beam[k]) : upto;
         for (; b < nb; ++b) acc += a.log_eps;  // slam/mcl.cpp:69-74, a beam beyond the 4 sigma clamp
         if (k < n)
         {
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_weights_L(WeightArgs a)
 {
     __shared__ KwlList kwl;
     double* val = kwl.val[threadIdx.x >> 6];
-    unsigned short* beam = kwl.beam[threadIdx.x >> 6];
+    int* beam = kwl.beam[threadIdx.x >> 6];
     int n_list = 0, b_done = 0;  // wave-uniform
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_weights_L(WeightArgs a)
         {
             const int k = n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
             val[k] = lw;
-            beam[k] = (unsigned short)b;
+            beam[k] = b;
         }
         n_list += __builtin_popcountll(m);
     }

@@ -162,6 +162,29 @@ def test_weights_localization(sa, raycaster, mapname, N, B, zmax, stddev):
     f.close()
 
 
+def test_weights_of_a_scan_longer_than_any_lds_row(sa):
+    """2000 beams (more than the 1536 the wave-per-particle kernel once kept as a row of doubles in LDS): its in-order sum now
+    comes from a short list that is flushed whenever the next 64 beams might not fit (kwl_flush), whatever the beam count.
+    Converged cloud (nearly every beam within 4 sigma: every group flushes) and a wide one (a handful of listed beams)."""
+    rng = np.random.default_rng(2000)
+    free = orc.load_map("floor_plan")
+    g = (free * 255).astype(np.uint8)
+    rows, cols = g.shape
+    true = [cols * 0.4, rows * 0.45, 0.3]
+    B = 2000
+    ang, dist = orc.make_scan(free, true, OFFSET, B, max_dist=500.0)
+    for spread, N in ((0.3, 96), (200.0, 160)):
+        x, y, th = true[0] + spread * rng.standard_normal(N), true[1] + spread * rng.standard_normal(N), true[2] + 0.01 * spread * rng.standard_normal(N)
+        for log_domain in (False, True):
+            f = sa.Filter(N, rows, cols, raycaster=RAYCASTERS["beam_lanes"], weight_domain=sa.capi.WEIGHT_LOG if log_domain else sa.capi.WEIGHT_LINEAR)
+            f.set_map(g)
+            f.set_poses(x, y, th)
+            f.update_weights(ang, dist, 5.0, 500.0, OFFSET)
+            ow, _ = orc.update_weights(x, y, th, g, ang, dist, 5.0, 500.0, OFFSET, math=orc.DET, n_threads=8, log_domain=log_domain)
+            assert_bits(f.weights(), ow, f"weights, spread {spread}, log domain {log_domain}")
+            f.close()
+
+
 @pytest.mark.parametrize("N", [4097, 333])     # particle lanes with a ragged last block / beam lanes
 @pytest.mark.parametrize("mapname,zmax", [("floor_plan", 500.0), ("floor_plan", 3.2), ("tiny", 40.0), ("tiny", 0.6)])
 def test_weights_hostile_poses(sa, N, mapname, zmax):
