@@ -132,8 +132,9 @@ def physical_roofline(kernel_names, kernel_ms, f64_key):
     profiles/run_profile.sh with rocprofv3 --pmc in runs of their own) and the kernel's duration measured live in THIS run.
     Quoted only while the kernel sources are the ones the counters were taken from (fingerprint), else None.
       hbm: measured bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) / duration, as a fraction of 8 TB/s and of 6.29 TB/s;
-      valu: wavefront VALU instructions per launch, weighed with the static share of 64-bit instructions (two issue
-            slots each on gfx950: profiles/valu_f64_share.json), over the issue slots of 1024 SIMDs in that duration."""
+      valu: wavefront VALU instructions per launch x 4 cycles (a 16-lane SIMD issues one wavefront instruction per 4 cycles), and
+            weighed with the static share of 64-bit instructions at their measured rates (profiles/valu_f64_share.json,
+            profiles/ubench_r03.txt), over the cycles of 1024 SIMDs in that duration."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_weights_kernel.json")))
         fp = source_fingerprint()
@@ -157,10 +158,16 @@ def physical_roofline(kernel_names, kernel_ms, f64_key):
             slots = N_SIMD * CLOCK_HZ * kernel_ms * 1e-3
             v = {"wave_valu_insts_per_launch": valu, "wave_salu_insts_per_launch": salu, "simd_cycles_available": slots,
                  "f64_share_static": share, "valu_insts_per_cycle_per_simd": valu / slots}
+            # a wavefront VALU instruction holds its 16-lane SIMD for 4 cycles; measured on this chip (profiles/ubench_r03.txt, 4 wavefronts
+            # per SIMD, 2.4 GHz nominal): f64 add/fma/mul/cvt 4.6-4.9 cycles, 32-bit integer and float 3.2-3.5 (NOT two slots per f64
+            # instruction, as rounds 1-2 assumed)
+            v["valu_busy_frac"] = valu * 4.0 / slots
             if share is not None:
-                v["issue_slot_frac"] = valu * (1.0 + share) / slots
-                v["note"] = ("issue_slot_frac = VALU wavefront instructions x (1 + 64-bit share) / (1024 SIMDs x 2.4 GHz x kernel time): a 64-bit "
-                             "VALU instruction holds the SIMD for two slots; SALU and memory instructions issue beside it")
+                v["valu_busy_frac_measured_rates"] = valu * (share * 4.9 + (1.0 - share) * 3.4) / slots
+            v["note"] = ("valu_busy_frac = VALU wavefront instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time): the share of the kernel's "
+                         "duration in which the vector ALUs are issuing; ..._measured_rates weighs the static 64-bit share with 4.9 cycles and the rest "
+                         "with 3.4 (profiles/ubench_r03.txt); SALU and memory instructions issue beside them; the clock under load may be below "
+                         "the nominal 2.4 GHz, which makes both fractions lower bounds")
             out["valu"] = v
         return out
     except Exception:

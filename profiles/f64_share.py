@@ -1,6 +1,6 @@
 """Static share of 64-bit VALU instructions in the hot kernels (gfx950 disassembly of `hipcc -save-temps`), written to
-profiles/valu_f64_share.json with the fingerprint of the sources.  An f64 (or 64-bit integer) VALU instruction occupies
-the SIMD for two issue slots on gfx950 where a 32-bit one takes one, so bench.py weighs the wavefront instruction counts of
+profiles/valu_f64_share.json with the fingerprint of the sources.  An f64 VALU instruction occupies the SIMD for 4.6-4.9
+cycles on gfx950 where a 32-bit one takes 3.2-3.5 (profiles/ubench_r03.txt), so bench.py weighs the wavefront instruction counts of
 the SQ counters with this share (static: every instruction of the kernel body counted once, not by how often it runs).
 Usage: python profiles/f64_share.py   (needs hipcc; ~1 minute)"""
 import hashlib
@@ -12,7 +12,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"k_rays_pl": "k_rays_plILi5ELb0ELb0EE", "k_sum_lw": "k_sum_lw", "k_weights_L<0>": "k_weights_LILi0EE",
+KERNELS = {"k_rays_pl": "k_rays_plILi5ELb0ELb0EE", "k_sum_lw": "k_sum_lw", "k_weights_L<0>": "k_weights_LILi0ELi6EE",
            "k_weights_S2<tiled>": "k_weights_S2ILb1ELb0ELb0EE", "k_weights_S2F": "k_weights_S2FE"}
 
 

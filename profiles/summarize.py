@@ -166,7 +166,7 @@ def weights_traffic(base):
         r = cur.execute("select avg(value) from counters_collection where counter_name=? and kernel_name like ? and grid_size=?",
                         (counter, like, big)).fetchone()
         return (float(r[0]) if r and r[0] is not None else None), big
-    (fk, big), (wk, _) = avg_big(f[0], "FETCH_SIZE", "%k_weights_L<0>%"), avg_big(w[0], "WRITE_SIZE", "%k_weights_L<0>%")
+    (fk, big), (wk, _) = avg_big(f[0], "FETCH_SIZE", "%k_weights_L<0,%"), avg_big(w[0], "WRITE_SIZE", "%k_weights_L<0,%")
     if fk is not None and wk is not None and big and big > 100_000_000:
         out["kernels"]["weighting kernel of the 16384^2 shard (k_weights_L<0>, 12.5 M particles)"] = {
             "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes": 2.0 * fk * 1024.0 + wk * 1024.0}
@@ -183,7 +183,7 @@ def weights_traffic(base):
             return {c: float(a) for c, a in cur.execute(f"select counter_name, avg(value) from counters_collection where {cond} group by counter_name", args)}
         SQ_KEYS = ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")
         for name, like, big in (("k_rays_pl", "%k_rays_pl<5, false, false>%", False), ("k_sum_lw", "%k_sum_lw%", False),
-                                ("weighting kernel of the 16384^2 shard (k_weights_L<0>, 12.5 M particles)", "%k_weights_L<0>%", True)):
+                                ("weighting kernel of the 16384^2 shard (k_weights_L<0>, 12.5 M particles)", "%k_weights_L<0,%", True)):
             v = sq_of(like, big)
             if v and name in out["kernels"]:
                 out["kernels"][name]["sq"] = {k: v[k] for k in SQ_KEYS if k in v}
