@@ -232,8 +232,23 @@ DM_HD double dm_cos(double x)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Natural logarithm.  x = 2^k (1+f), sqrt(2)/2 < 1+f < sqrt(2); log(1+f) through s = f/(2+f).
-DM_HD double dm_log(double x)
+// exp and log, round 3: table driven, no division (the schemes of Tang's table-driven exp / log, as used by today's libms: a
+// 128-entry table and a short polynomial), because the particle-lane ray kernel is bound by VALU issue and the fdlibm forms
+// (a rational function for exp, f/(2+f) for log: an 11-instruction division each) were a sixth of its instructions.
+// Tables: detmath_tables.h, generated from their definitions by tools/gen_detmath_tables.py.  Accuracy < 1 ulp
+// (tests/test_detmath.py, against 80-bit long double); same bits on host and device as before.
+#include "detmath_tables.h"
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ static const uint64_t dm_exp_tab[256] = {DM_EXP_TABLE};
+__device__ __constant__ static const uint64_t dm_log_tab[256] = {DM_LOG_TABLE};
+#else
+static const uint64_t dm_exp_tab[256] = {DM_EXP_TABLE};
+static const uint64_t dm_log_tab[256] = {DM_LOG_TABLE};
+#endif
+
+// log by fdlibm's scheme: x = 2^k (1+f), sqrt(2)/2 < 1+f < sqrt(2); log(1+f) through s = f/(2+f).  Kept for arguments near 1,
+// where the result is small and the table form would lose relative accuracy.  x: positive, finite, normal.
+DM_HD double dm_log_near1(double x)
 {
     const double ln2_hi = dm_from_bits(0x3FE62E42FEE00000ull);  // 6.93147180369123816490e-01
     const double ln2_lo = dm_from_bits(0x3DEA39EF35793C76ull);  // 1.90821492927058770002e-10
@@ -244,34 +259,15 @@ DM_HD double dm_log(double x)
     const double Lg5 = DM_KC(0x3FC7466496CB03DEull, x);     // 1.818357216161805012e-01
     const double Lg6 = DM_KC(0x3FC39A09D078C69Full, x);     // 1.531383769920937332e-01
     const double Lg7 = DM_KC(0x3FC2F112DF3E5244ull, x);     // 1.479819860511658591e-01
-
     uint64_t u = dm_bits(x);
     uint32_t hx = (uint32_t)(u >> 32);
-    int k = 0;
-    if (hx < 0x00100000u || (hx >> 31))
-    {
-        if ((u << 1) == 0) return -1.0 / (x * x);  // log(+-0) = -inf
-        if (hx >> 31) return (x - x) / 0.0;        // log(-#) = NaN
-        k -= 54;                                   // subnormal: scale up
-        x *= dm_from_bits(0x4350000000000000ull);  // 2^54
-        u = dm_bits(x);
-        hx = (uint32_t)(u >> 32);
-    }
-    else if (hx >= 0x7ff00000u)
-    {
-        return x;
-    }
-    else if (hx == 0x3ff00000u && (u << 32) == 0)
-    {
-        return 0.0;
-    }
+    if (hx == 0x3ff00000u && (u << 32) == 0) return 0.0;
     // reduce x into [sqrt(2)/2, sqrt(2))
     hx += 0x3ff00000u - 0x3fe6a09eu;
-    k += (int)(hx >> 20) - 0x3ff;
+    const int k = (int)(hx >> 20) - 0x3ff;
     hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
     u = ((uint64_t)hx << 32) | (u & 0xffffffffull);
     x = dm_from_bits(u);
-
     const double f = x - 1.0;
     const double hfsq = 0.5 * f * f;
     const double s = f / (2.0 + f);
@@ -284,21 +280,65 @@ DM_HD double dm_log(double x)
     return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
 }
 
+// Natural logarithm.  x = 2^k z with z in [0.6875, 1.375); the 7 bits below the exponent of bits(z) - bits(0.6875) pick
+// (invc, logc) with invc near 1/z and logc = -log(invc) to 2^-11 of its last place; r = z invc - 1 (one fma, |r| < 0.0042) and
+// log(x) = k ln2 + logc + log1p(r), the last as r - r^2/2 + ... + r^7/7 (truncation below 1e-20), with the leading sum
+// k ln2_hi + logc + r kept as a head and an exact tail.
+DM_HD double dm_log(double x)
+{
+    const double ln2_hi = dm_from_bits(0x3FE62E42FEE00000ull);  // 21 trailing zero bits: k * ln2_hi is exact
+    const double ln2_lo = dm_from_bits(0x3DEA39EF35793C76ull);
+    uint64_t u = dm_bits(x);
+    uint32_t hx = (uint32_t)(u >> 32);
+    int k0 = 0;
+    if (hx < 0x00100000u || (hx >> 31))
+    {
+        if ((u << 1) == 0) return -1.0 / (x * x);  // log(+-0) = -inf
+        if (hx >> 31) return (x - x) / 0.0;        // log(-#) = NaN
+        k0 = -54;                                  // subnormal: scale up
+        x *= dm_from_bits(0x4350000000000000ull);  // 2^54
+        u = dm_bits(x);
+        hx = (uint32_t)(u >> 32);
+    }
+    else if (hx >= 0x7ff00000u)
+    {
+        return x;
+    }
+    // [0.9375, 1.0625): the result is small
+    if (hx - 0x3fee0000u < 0x3ff10000u - 0x3fee0000u && k0 == 0) return dm_log_near1(x);
+    const uint64_t tmp = u - 0x3FE6000000000000ull;
+    const int i = (int)((tmp >> 45) & 127);
+    const int k = (int)((int64_t)tmp >> 52) + k0;
+    const double z = dm_from_bits(u - (tmp & 0xFFF0000000000000ull));
+    const double invc = dm_from_bits(dm_log_tab[2 * i]), logc = dm_from_bits(dm_log_tab[2 * i + 1]);
+    const double r = dm_fma(z, invc, -1.0);
+    const double kd = (double)k;
+    // k ln2_hi + logc + r as a head and its exact rounding errors (two Fast2Sums: |k ln2_hi| > |logc| unless k = 0, and
+    // |w| >= |logc| - ... > |r|: arguments whose logc is smaller than r went to dm_log_near1)
+    const double P = kd * ln2_hi;  // exact
+    const double w = P + logc;
+    const double ew = (P - w) + logc;
+    const double hi = w + r;
+    const double lo = dm_fma(kd, ln2_lo, ((w - hi) + r) + ew);
+    // r^2 (A2 + r A3 + r^2 (A4 + r A5 + r^2 (A6 + r A7))), A_n = (-1)^(n+1) / n.  (DM_KC: the compiler otherwise keeps every
+    // constant in a vector register pair for the whole kernel, whether written as a literal or not: measured again in round 3,
+    // 75 -> 86 registers in k_rays_pl and scratch in the other ray kernels)
+    const double A3 = DM_KC(0x3FD5555555555555ull, x);   //  1/3
+    const double A4 = DM_KC(0xBFD0000000000000ull, x);   // -1/4
+    const double A5 = DM_KC(0x3FC999999999999Aull, x);   //  1/5
+    const double A6 = DM_KC(0xBFC5555555555555ull, x);   // -1/6
+    const double A7 = DM_KC(0x3FC2492492492492ull, x);   //  1/7
+    const double r2 = r * r;
+    const double p = dm_fma(r2, dm_fma(r2, dm_fma(r, A7, A6), dm_fma(r, A5, A4)), dm_fma(r, A3, -0.5));
+    return dm_fma(r2, p, lo) + hi;
+}
+
 // ---------------------------------------------------------------------------------------------
-// exp(x): x = k ln2 + r, |r| <= 0.5 ln2; exp(r) through the rational form 1 + 2r/(2-c(r)).
+// exp(x): x = (128 m + j) ln2/128 + r, |r| <= ln2/256; exp(x) = 2^m 2^(j/128) exp(r), 2^(j/128) = hi_j (1 + tail_j) from the
+// table, exp(r) - 1 = r + r^2/2 + r^3/6 + r^4/24 + r^5/120 (truncation below 6e-19).
 DM_HD double dm_exp(double x)
 {
-    const double ln2hi = dm_from_bits(0x3FE62E42FEE00000ull);
-    const double ln2lo = dm_from_bits(0x3DEA39EF35793C76ull);
-    const double invln2 = dm_from_bits(0x3FF71547652B82FEull);  // 1.44269504088896338700e+00
-    const double P1 = DM_KC(0x3FC555555555553Eull, x);      //  1.66666666666666019037e-01
-    const double P2 = DM_KC(0xBF66C16C16BEBD93ull, x);      // -2.77777777770155933842e-03
-    const double P3 = DM_KC(0x3F11566AAF25DE2Cull, x);      //  6.61375632143793436117e-05
-    const double P4 = DM_KC(0xBEBBBD41C5D26BF1ull, x);      // -1.65339022054652515390e-06
-    const double P5 = DM_KC(0x3E66376972BEA4D0ull, x);      //  4.13813679705723846039e-08
-
     uint32_t hx = dm_hi(x);
-    const int sign = (int)(hx >> 31);
     hx &= 0x7fffffffu;
     if (hx >= 0x4086232bu)
     {  // |x| >= 708.39 or NaN
@@ -306,31 +346,30 @@ DM_HD double dm_exp(double x)
         if (x > 709.782712893383973096) return x * dm_from_bits(0x7FE0000000000000ull);  // overflow
         if (x < -745.13321910194110842) return 0.0;                                      // underflow
     }
-    double hi, lo;
-    int k;
-    if (hx > 0x3fd62e42u)
-    {  // |x| > 0.5 ln2
-        if (hx >= 0x3ff0a2b2u)
-            k = (int)(invln2 * x + (sign ? -0.5 : 0.5));
-        else
-            k = 1 - sign - sign;
-        hi = x - (double)k * ln2hi;  // k*ln2hi is exact
-        lo = (double)k * ln2lo;
-        x = hi - lo;
+    if (hx <= 0x3e300000u) return 1.0 + x;  // |x| <= 2^-28
+    const double shift = dm_from_bits(0x4338000000000000ull);  // 1.5 * 2^52: (z + shift) - shift = z rounded to an integer
+    const double z = x * dm_from_bits(DM_EXP_INV_LN2_N);
+    const double kd = (z + shift) - shift;
+    const int ki = (int)kd;
+    double r = dm_fma(kd, dm_from_bits(DM_EXP_NEG_LN2_HI_N), x);  // exact: 35-bit constant, |kd| < 2^18
+    r = dm_fma(kd, dm_from_bits(DM_EXP_NEG_LN2_LO_N), r);
+    const int j = ki & 127, m = ki >> 7;
+    const double tail = dm_from_bits(dm_exp_tab[2 * j]);
+    const uint64_t hbits = dm_exp_tab[2 * j + 1];
+    // r + r^2 (1/2 + r / 6) + r^4 (1/24 + r / 120)
+    const double C3 = DM_KC(0x3FC5555555555555ull, x);  // 1/6
+    const double C4 = DM_KC(0x3FA5555555555555ull, x);  // 1/24
+    const double C5 = DM_KC(0x3F81111111111111ull, x);  // 1/120
+    const double r2 = r * r;
+    const double t = dm_fma(r2 * r2, dm_fma(r, C5, C4), dm_fma(r2, dm_fma(r, C3, 0.5), r));
+    const double tmp = tail + t;
+    if (m < -1020 || m > 1020)
+    {  // the scale 2^m is not a normal number (or close): scale in two steps
+        const int adj = m < 0 ? 100 : -8;
+        const double s2 = dm_from_bits(hbits + ((uint64_t)(int64_t)(m + adj) << 52));
+        const double y = dm_fma(s2, tmp, s2);
+        return y * dm_from_bits((uint64_t)(0x3ff - adj) << 52);
     }
-    else if (hx > 0x3e300000u)
-    {  // |x| > 2^-28
-        k = 0;
-        hi = x;
-        lo = 0.0;
-    }
-    else
-    {
-        return 1.0 + x;
-    }
-    const double xx = x * x;
-    const double c = x - xx * dm_fma(xx, dm_fma(xx, dm_fma(xx, dm_fma(xx, P5, P4), P3), P2), P1);
-    const double y = 1.0 + (x * c / (2.0 - c) - lo + hi);
-    if (k == 0) return y;
-    return dm_scalbn(y, k);
+    const double scale = dm_from_bits(hbits + ((uint64_t)(int64_t)m << 52));
+    return dm_fma(scale, tmp, scale);
 }

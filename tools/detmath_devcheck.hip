@@ -1,0 +1,44 @@
+// detmath_devcheck.hip — dm_exp / dm_log / dm_sincos on the device against the same functions on the host, bit for bit.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/libs/detmath_devcheck tools/detmath_devcheck.hip   (also with -O1)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../slam_amd/csrc/detmath.h"
+__global__ void k(const double* x, double* e, double* l, double* s, double* c, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    e[i] = dm_exp(x[i]);
+    l[i] = dm_log(dm_fabs(x[i]) + 1e-300);
+    dm_sincos(x[i], &s[i], &c[i]);
+}
+int main()
+{
+    const int n = 1 << 22;
+    std::vector<double> x(n), e(n), l(n), s(n), c(n);
+    srand48(7);
+    for (int i = 0; i < n; ++i)
+    {
+        const double u = drand48();
+        x[i] = i % 4 == 0 ? -8.0 * u : (i % 4 == 1 ? (u - 0.5) * 1400 : (i % 4 == 2 ? 0.1 + 0.2 * u : (u - 0.5) * 4));
+    }
+    double *dx, *de, *dl, *ds, *dc;
+    (void)hipMalloc(&dx, n * 8); (void)hipMalloc(&de, n * 8); (void)hipMalloc(&dl, n * 8); (void)hipMalloc(&ds, n * 8); (void)hipMalloc(&dc, n * 8);
+    (void)hipMemcpy(dx, x.data(), n * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dx, de, dl, ds, dc, n);
+    (void)hipMemcpy(e.data(), de, n * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(l.data(), dl, n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(s.data(), ds, n * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(c.data(), dc, n * 8, hipMemcpyDeviceToHost);
+    long be = 0, bl = 0, bs = 0;
+    for (int i = 0; i < n; ++i)
+    {
+        double hs, hc;
+        dm_sincos(x[i], &hs, &hc);
+        const double he = dm_exp(x[i]), hl = dm_log(dm_fabs(x[i]) + 1e-300);
+        if (dm_bits(he) != dm_bits(e[i]) && !(he != he && e[i] != e[i])) { if (!be) printf("exp(%a): host %a device %a\n", x[i], he, e[i]); ++be; }
+        if (dm_bits(hl) != dm_bits(l[i])) { if (!bl) printf("log(%a): host %a device %a\n", dm_fabs(x[i]) + 1e-300, hl, l[i]); ++bl; }
+        if (dm_bits(hs) != dm_bits(s[i]) || dm_bits(hc) != dm_bits(c[i])) ++bs;
+    }
+    printf("%d arguments: exp differs %ld, log differs %ld, sincos differs %ld\n", n, be, bl, bs);
+    return (be || bl || bs) ? 1 : 0;
+}
