@@ -1,10 +1,10 @@
 // detmath_devcheck.hip — dm_exp / dm_log / dm_sincos on the device against the same functions on the host, bit for bit.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/libs/detmath_devcheck tools/detmath_devcheck.hip   (also with -O1)
+// Built by `make -C tests/host_cpp detmath_devcheck` (build()); run by tests/test_host_cpp.py on the GPU.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../slam_amd/csrc/detmath.h"
+#include "../../slam_amd/csrc/detmath.h"
 __global__ void k(const double* x, double* e, double* l, double* s, double* c, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -37,6 +37,38 @@ def test_exp_log(orc):
     assert orc.detmath(3, [1.0])[0] == 0.0
 
 
+def test_exp_log_tables_edges_and_special_values(orc):
+    """The table-driven exp / log of round 3: the seams of their tables (arguments one place either side of every sub-interval of
+    log's z range and of every 2^(j/128) step of exp), the hand-over to fdlibm's log at 0.9375 and 1.0625, subnormal arguments
+    and results, and the special values."""
+    off = np.uint64(0x3FE6000000000000)
+    edges = (off + (np.arange(129, dtype=np.uint64) << np.uint64(45)))
+    z = np.concatenate([(edges + np.uint64(d)).view(np.float64) for d in (0, 1, 2)] + [(edges - np.uint64(d)).view(np.float64) for d in (1, 2)])
+    y = np.concatenate([z * s for s in (1.0, 0.125, 2.0 ** -300, 2.0 ** 500, 2.0 ** -1022)] + [[0.9375, np.nextafter(0.9375, 0), 1.0625, np.nextafter(1.0625, 2),
+                        np.nextafter(1.0, 0), np.nextafter(1.0, 2), 5e-324, 1e-310, 2.2250738585072014e-308, 1.7976931348623157e308]])
+    assert ulp_err(orc.detmath(3, y), y, np.log) < 0.6
+    near1 = rng.uniform(0.93, 1.07, 200000)
+    assert ulp_err(orc.detmath(3, near1), near1, np.log) < 0.6
+    k = np.arange(-137000, 131000, 37, dtype=np.float64)
+    x = np.concatenate([k * (np.log(2.0) / 128) * (1 + e) for e in (0.0, 1e-16, -1e-16, 3e-3 / np.maximum(np.abs(k), 1))])
+    x = x[(x > -708.0) & (x < 709.7)]
+    assert ulp_err(orc.detmath(2, x), x, np.exp) < 0.52
+    sub = rng.uniform(-745.0, -708.4, 50000)   # subnormal results: one more rounding
+    got = orc.detmath(2, sub)
+    assert np.all(np.abs(got.astype(np.longdouble) - np.exp(sub.astype(np.longdouble))) <= 1.0 * 5e-324)
+    inf, nan = np.inf, np.nan
+    sv = orc.detmath(3, [0.0, -0.0, -1.0, inf, nan, 1.0])
+    assert sv[0] == -inf and sv[1] == -inf and np.isnan(sv[2]) and sv[3] == inf and np.isnan(sv[4]) and sv[5] == 0.0
+    ev = orc.detmath(2, [0.0, -0.0, inf, -inf, nan, 1e-300, -1e-300, 709.782712893384, 709.7827128933841])
+    assert ev[0] == 1.0 and ev[1] == 1.0 and ev[2] == inf and ev[3] == 0.0 and np.isnan(ev[4]) and ev[5] == 1.0 and ev[6] == 1.0
+    assert np.isfinite(ev[7]) and ev[8] == inf
+    # monotone where the filter uses them: the likelihood's arguments
+    q = np.linspace(-8.0, 0.0, 400001)
+    assert np.all(np.diff(orc.detmath(2, q)) >= 0)
+    p = np.linspace(0.1, 0.3, 400001)
+    assert np.all(np.diff(orc.detmath(3, p)) >= 0)
+
+
 def test_fmod_is_exact(orc):
     x = np.concatenate([rng.uniform(-100, 100, 200000), rng.uniform(-1e9, 1e9, 50000), [0.0, 2 * np.pi, -2 * np.pi, 7.0]])
     assert np.array_equal(orc.detmath(4, x), orc.libm(4, x))
