@@ -386,21 +386,28 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_rays_pl(WeightArgs a)
     if (DIRECT && real) a.w[p] = a.log_domain ? acc : dm_exp(acc);
 }
 
-// The cloud's bounding box from 256 of its particles into box[which] (see k_order_keys): launched before the first
-// weighting pass after the poses were set or seeded, so that even that pass is ordered for the cloud it meets.
-// box_host: the same four numbers in pinned host memory (a store over PCIe, nobody waits for it): the host reads them
-// some passes later to choose the kernel SHAPE for the cloud (do_weights).
-__global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, const double* y, int* box, int which, int* box_host)
+// The cloud's extent from 256 of its particles (called by the 256 threads of one workgroup): bounding box in cells into
+// box[4 * which .. +3], extent of the headings in 1/65536 turns into box[8 + which]; the box also to pinned host memory.
+// 256 particles spread evenly over the index range (after a sorted resample the FIRST 256 are the heaviest particles,
+// clustered however wide the cloud is; a caller that sets poses in place order has one corner there).
+__device__ __forceinline__ void cloud_extent_sample(int64_t n, const double* x, const double* y, const double* th, int* box, int which, int* box_host)
 {
     __shared__ int part[4][4];
-    // 256 particles spread evenly over the index range (after a sorted resample the FIRST 256 are the heaviest particles,
-    // clustered however wide the cloud is; a caller that sets poses in place order has one corner there)
+    __shared__ float hpart[4][4];
     const int64_t p = n > 256 ? (int64_t)(((unsigned long long)threadIdx.x * (unsigned long long)n) >> 8) : (int64_t)threadIdx.x;
     int lx = 0x7fffffff, ly = 0x7fffffff, hx = -0x7fffffff - 1, hy = -0x7fffffff - 1;
+    // headings as fractions of a turn, twice: as they are and half a turn on (a cloud across the seam of one is compact in the other)
+    float a0 = 2.0f, a1 = -1.0f, b0 = 2.0f, b1 = -1.0f;
     if (p < n)
     {
         lx = hx = slam_f2i(x[p]);
         ly = hy = slam_f2i(y[p]);
+        const float t = (float)(th[p] * 0.15915494309189535);
+        if (t > -64.0f && t < 64.0f)
+        {
+            a0 = a1 = t - __builtin_floorf(t);
+            b0 = b1 = (t + 0.5f) - __builtin_floorf(t + 0.5f);
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1)
@@ -409,11 +416,17 @@ __global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, c
         ly = min(ly, __shfl_xor(ly, o));
         hx = max(hx, __shfl_xor(hx, o));
         hy = max(hy, __shfl_xor(hy, o));
+        a0 = fminf(a0, __shfl_xor(a0, o));
+        a1 = fmaxf(a1, __shfl_xor(a1, o));
+        b0 = fminf(b0, __shfl_xor(b0, o));
+        b1 = fmaxf(b1, __shfl_xor(b1, o));
     }
     if ((threadIdx.x & 63) == 0)
     {
         int* q = part[threadIdx.x >> 6];
         q[0] = lx, q[1] = ly, q[2] = hx, q[3] = hy;
+        float* g = hpart[threadIdx.x >> 6];
+        g[0] = a0, g[1] = a1, g[2] = b0, g[3] = b1;
     }
     __syncthreads();
     if (threadIdx.x == 0)
@@ -423,8 +436,21 @@ __global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, c
         cur[1] = min(min(part[0][1], part[1][1]), min(part[2][1], part[3][1]));
         cur[2] = max(max(part[0][2], part[1][2]), max(part[2][2], part[3][2]));
         cur[3] = max(max(part[0][3], part[1][3]), max(part[2][3], part[3][3]));
+        const float ea = fmaxf(fmaxf(hpart[0][1], hpart[1][1]), fmaxf(hpart[2][1], hpart[3][1])) - fminf(fminf(hpart[0][0], hpart[1][0]), fminf(hpart[2][0], hpart[3][0]));
+        const float eb = fmaxf(fmaxf(hpart[0][3], hpart[1][3]), fmaxf(hpart[2][3], hpart[3][3])) - fminf(fminf(hpart[0][2], hpart[1][2]), fminf(hpart[2][2], hpart[3][2]));
+        const float e = fminf(ea, eb);
+        box[8 + which] = e >= 0.0f ? (int)(fminf(e, 1.0f) * 65536.0f) : 65536;  // (no usable heading: a full turn)
         if (box_host) *reinterpret_cast<int4*>(box_host) = make_int4(cur[0], cur[1], cur[2], cur[3]);  // one 16-byte store: never torn
     }
+}
+
+// The cloud's extent into box[which] (see k_order_keys): launched before the first
+// weighting pass after the poses were set or seeded, so that even that pass is ordered for the cloud it meets.
+// box_host: the same four numbers in pinned host memory (a store over PCIe, nobody waits for it): the host reads them
+// some passes later to choose the kernel SHAPE for the cloud (do_weights).
+__global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, const double* y, const double* th, int* box, int which, int* box_host)
+{
+    cloud_extent_sample(n, x, y, th, box, which, box_host);
 }
 
 // Pose-coherent order for k_rays_pl.  The weight of a particle does not depend on which lane
@@ -435,7 +461,7 @@ __global__ void __launch_bounds__(256) k_order_box(int64_t n, const double* x, c
 __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, const double* y, const double* th,
                                                     int mode, int key_bits, uint32_t* keys, int32_t* ident,
                                                     unsigned long long* stats, const double* scan_src, double* scan_dst,
-                                                    int scan_n, int* box, int pass_no, int wide_mode, int* box_host)
+                                                    int scan_n, int* box, int pass_no, int wide_mode, int* box_host, float scan_range)
 {
     // side job of the last workgroup: the new scan from its pinned host slot to the device (read by the kernels that
     // follow on the stream; saves the copy kernel and its launch gap)
@@ -471,40 +497,7 @@ __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, 
         const int* prev = box + 4 * ((pass_no + 1) & 1);
         const int bx0 = prev[0], by0 = prev[1], bx1 = prev[2], by1 = prev[3];
         if (bx1 >= bx0 && by1 >= by0 && ((double)bx1 - bx0 + 1.0) * ((double)by1 - by0 + 1.0) > 4194304.0) mode = wide_mode;
-        if (blockIdx.x == 0)
-        {
-            __shared__ int part[4][4];
-            int lx = 0x7fffffff, ly = 0x7fffffff, hx = -0x7fffffff - 1, hy = -0x7fffffff - 1;
-            const int64_t ps = n > 256 ? (int64_t)(((unsigned long long)threadIdx.x * (unsigned long long)n) >> 8) : p;  // (as k_order_box)
-            if (ps < n)
-            {
-                lx = hx = slam_f2i(x[ps]);
-                ly = hy = slam_f2i(y[ps]);
-            }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1)
-            {
-                lx = min(lx, __shfl_xor(lx, o));
-                ly = min(ly, __shfl_xor(ly, o));
-                hx = max(hx, __shfl_xor(hx, o));
-                hy = max(hy, __shfl_xor(hy, o));
-            }
-            if ((threadIdx.x & 63) == 0)
-            {
-                int* q = part[threadIdx.x >> 6];
-                q[0] = lx, q[1] = ly, q[2] = hx, q[3] = hy;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0)
-            {
-                int* cur = box + 4 * (pass_no & 1);
-                cur[0] = min(min(part[0][0], part[1][0]), min(part[2][0], part[3][0]));
-                cur[1] = min(min(part[0][1], part[1][1]), min(part[2][1], part[3][1]));
-                cur[2] = max(max(part[0][2], part[1][2]), max(part[2][2], part[3][2]));
-                cur[3] = max(max(part[0][3], part[1][3]), max(part[2][3], part[3][3]));
-                if (box_host) *reinterpret_cast<int4*>(box_host) = make_int4(cur[0], cur[1], cur[2], cur[3]);  // (see k_order_box)
-            }
-        }
+        if (blockIdx.x == 0) cloud_extent_sample(n, x, y, th, box, pass_no & 1, box_host);
     }
     if (p >= n) return;
     if (p < 3) stats[p] = 0;  // the pass's counters start at zero (saves a memset launch)
@@ -512,7 +505,29 @@ __global__ void __launch_bounds__(256) k_order_keys(int64_t n, const double* x, 
     // best for a converged cloud, 4 % over 2-cell tiles / 8 bits; a wide cloud prefers coarser headings)
     const int kind = mode & 15;
     const int tshift = ((mode >> 4) & 15) ? ((mode >> 4) & 15) - 1 : 2;
-    const int tbits = ((mode >> 8) & 15) ? ((mode >> 8) & 15) : 10;
+    int tbits = ((mode >> 8) & 15) ? ((mode >> 8) & 15) : 10;
+    // Heading buckets as wide as the cloud wants them (kind 3 with no bucket count given, scan_range > 0; round 3).  The 64
+    // particles of a wavefront should differ as little in heading as in place: with buckets d (radians) wide, 64 consecutive
+    // particles of a bucket lie within L = sqrt(64 A H / (n d)) cells (A: the cloud's area, H: its heading extent), and their
+    // rays end d R and L apart at the scan's mean range R; equal at d^3 = 64 A H / (n R^2).  That gives the 10 bits a
+    // converged cloud was tuned to, 6 for the sigma-25 cloud of the bench (1.00 -> 0.87 ms; 10 bits there, 6 bits on the
+    // converged cloud: +13 % and +10 %), 8-9 for the Gaussian cloud of the 8192^2 shard.  From the extent the pass before left.
+    if (kind == 3 && ((mode >> 8) & 15) == 0 && scan_range > 0.0f && wide_mode)
+    {
+        const int w = (pass_no + 1) & 1;
+        const int* prev = box + 4 * w;
+        if (prev[2] >= prev[0] && prev[3] >= prev[1])
+        {
+            const float A = ((float)prev[2] - (float)prev[0] + 1.0f) * ((float)prev[3] - (float)prev[1] + 1.0f);
+            const float H = fmaxf((float)box[8 + w], 1.0f) * (1.0f / 65536.0f);  // turns
+            const float R = fmaxf(scan_range, 1.0f);
+            // d in turns: d^3 = 64 A H / (n R^2 (2 pi)^2)
+            const float d3 = 64.0f * A * H / ((float)n * R * R * 39.478418f);
+            const float bits = -__builtin_log2f(fmaxf(d3, 1.0e-30f)) * (1.0f / 3.0f);
+            const int bi = (int)(bits + 0.5f);
+            tbits = bi < 4 ? 4 : (bi > 10 ? 10 : bi);
+        }
+    }
     const int tshift_y = ((mode >> 12) & 15) ? ((mode >> 12) & 15) - 1 : tshift;  // (tiles may be wider than tall: a cache line runs along x)
     const int nb = (key_bits - tbits) >> 1;  // tile bits per axis; the key has tbits + 2 nb <= key_bits bits
     const unsigned tmask = (1u << nb) - 1u;

@@ -271,6 +271,7 @@ struct Tuning
     int select_fuse; // SLAM_SELECT_FUSE: 1 = 4097..262144 particles: k_select rebuilds the upper levels of the running sum itself and the weight
                      // sort's last kernel gathers the states (default: three launches fewer per step), 0 = k_scan_upper + k_downsweep, k_gather
     int defer_fast;  // SLAM_DEFER_FAST: 1 = the weights-only kernel k_weights_S2F for the first half (default), 0 = k_weights_S2<DEFER>
+    int order_adapt; // SLAM_PL_ORDER_ADAPT: 1 = heading buckets of the pose-coherent order sized from the cloud's extent (default), 0 = 10 bits
 };
 const Tuning& tuning()
 {
@@ -280,7 +281,7 @@ const Tuning& tuning()
     };
     static const Tuning t = {env_int("SLAM_PL_ORDER", 3), env_int("SLAM_PL_ORDER_BITS", 32), env_int("SLAM_PL_SEG", 0),
                              env_int("SLAM_PL_WAVES", 5), env_int("SLAM_PL_DIRECT_MIN", 8192), env_int("SLAM_CONE_PLANES", 1), env_int("SLAM_SCAN_FUSE", 1), env_int("SLAM_S_KERNEL", 0),
-                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 4 | (7 << 4) | (8 << 8)), env_int("SLAM_PL_ORDER_SPARSE", 4 | (7 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1), env_int("SLAM_DEFER", 1), env_int("SLAM_SELECT_FUSE", 1), env_int("SLAM_DEFER_FAST", 1)};
+                             env_int("SLAM_SORT_IMPL", 3), env_int("SLAM_ORDER_COARSE", 1), env_int("SLAM_SS_LDS_CAP", sortk::GROUP_CAP), env_int("SLAM_FAST_DIV", 1), env_int("SLAM_RAY_CLAMP_LIMIT", 1), env_int("SLAM_CONE_BUILD", 1), env_int("SLAM_PL_ORDER_WIDE", 4 | (7 << 4) | (8 << 8)), env_int("SLAM_PL_ORDER_SPARSE", 4 | (7 << 4) | (6 << 8)), env_int("SLAM_BEAM_CELLS", 4), env_int("SLAM_TILE_FUSE", 1), env_int("SLAM_DEFER", 1), env_int("SLAM_SELECT_FUSE", 1), env_int("SLAM_DEFER_FAST", 1), env_int("SLAM_PL_ORDER_ADAPT", 1)};
     return t;
 }
 
@@ -366,9 +367,10 @@ int ensure_order_box(slam_mcl* h)
             return rc;
     }
     if (h->obox) return SLAM_OK;
-    if ((rc = dev_alloc(&h->obox, 8))) return rc;
-    // both boxes empty (max < min): the first pass keeps the default order and the default kernel shape
-    const int empty[8] = {0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1, 0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1};
+    if ((rc = dev_alloc(&h->obox, 16))) return rc;
+    // both boxes empty (max < min): the first pass keeps the default order and the default kernel shape; [8], [9]: heading extents
+    const int empty[16] = {0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1, 0x7fffffff, 0x7fffffff, -0x7fffffff - 1, -0x7fffffff - 1,
+                           65536,      65536,      0,               0,               0,          0,          0,               0};
     HIPCHK(hipMemcpy(h->obox, empty, sizeof(empty), hipMemcpyHostToDevice));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->obox_host), 4 * sizeof(int), hipHostMallocDefault));
     for (int k = 0; k < 4; ++k) h->obox_host[k] = empty[k];
@@ -383,7 +385,7 @@ int refresh_cloud_box(slam_mcl* h)
         return SLAM_OK;
     int rc = ensure_order_box(h);
     if (rc) return rc;
-    hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, (h->order_pass + 1) & 1, h->obox_host);
+    hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th, h->obox, (h->order_pass + 1) & 1, h->obox_host);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->poses_reset = false;
@@ -800,6 +802,15 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         }
         a.lw = h->lw;
         const int order_bits = tuning().order_bits;
+        // mean range at which the scan's rays end: sizes the heading buckets of the pose-coherent order (k_order_keys)
+        float scan_range = 0.0f;
+        if (h->scan_cache.size() >= 3 * (size_t)B)
+        {
+            double sum = 0.0;
+            const double* zz = h->scan_cache.data() + 2 * (size_t)B;
+            for (int b = 0; b < B; ++b) sum += zz[b] < max_dist ? zz[b] : max_dist;
+            scan_range = (float)(sum / B);
+        }
         bool ext_started = false;
         if (order_mode > 0)
         {
@@ -809,13 +820,13 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             }
             if (h->poses_reset)
             {  // poses set or seeded since the last pass: the box this pass reads comes from the new cloud
-                hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, (h->order_pass + 1) & 1, h->obox_host);
+                hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th, h->obox, (h->order_pass + 1) & 1, h->obox_host);
                 h->poses_reset = false;
             }
             hipExtLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, ext.a, nullptr, 0, h->n,
                                   h->x, h->y, h->th, order_mode, order_bits, h->okeys, h->oident, h->stats, h->scan_pending,
                                   h->scan_dev, (int)(h->scan_pending ? h->scan_pending_n : 0), h->obox, h->order_pass++ & 1,
-                                  order_bits == 32 ? tuning().order_wide : 0, h->obox_host);
+                                  order_bits == 32 ? tuning().order_wide : 0, h->obox_host, tuning().order_adapt ? scan_range : 0.0f);
             ext_started = true;
             if (h->scan_pending)
             {
@@ -880,7 +891,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
             // k_order_keys also leaves this pass's bounding box): wavefronts that run together read one part of the planes
             hipLaunchKernelGGL(slamk::k_order_keys, dim3((unsigned)cdiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th,
                                tuning().order_sparse, 32, h->okeys, h->oident, h->stats, (const double*)nullptr, h->scan_dev, 0, h->obox,
-                               h->order_pass++ & 1, tuning().order_sparse, h->obox_host);
+                               h->order_pass++ & 1, tuning().order_sparse, h->obox_host, 0.0f);
             h->poses_reset = false;
             {
                 int rc = sort_order_keys(h, 32);
@@ -890,7 +901,7 @@ int do_weights(slam_mcl* h, int B, double stddev, double max_dist, const double 
         }
         else if (sparse_cloud)
         {  // (no order: the box of this pass from a launch of its own)
-            hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->obox, h->order_pass++ & 1, h->obox_host);
+            hipLaunchKernelGGL(slamk::k_order_box, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->y, h->th, h->obox, h->order_pass++ & 1, h->obox_host);
             h->poses_reset = false;
         }
         // (6: the register budget of six wavefronts per SIMD, 80 VGPRs; measured on the 16384^2 shard: 95 VGPRs / 5 wavefronts
