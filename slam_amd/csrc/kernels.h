@@ -248,14 +248,18 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_weights_L(WeightArgs a)
     }
     const bool origin_in = slam_in_bounds(a.rows, a.cols, i0, j0);
     const unsigned off0 = (unsigned)(slam_mul24(i0, a.cols + 4) + j0 + 2 * (a.cols + 4) + 2);
-    for (int b0 = 0; b0 < a.B; b0 += 64)
+    for (int b0 = 0;; b0 += 64)
     {
-        if (n_list + 64 > KWL_LIST)
+        // (one instance of kwl_flush in the code: the last trip of this loop only adds what is listed)
+        const bool last_trip = b0 >= a.B;
+        if (last_trip || n_list + 64 > KWL_LIST)
         {  // the next group might not fit: add what is listed (everything before b0) now
-            acc = kwl_flush<VARIANT == 0>(a, val, beam, n_list, b_done, b0, acc, lane);
+            const int upto = last_trip ? a.B : b0;
+            acc = kwl_flush<VARIANT == 0>(a, val, beam, n_list, b_done, upto, acc, lane);
             n_list = 0;
-            b_done = b0;
+            b_done = upto;
         }
+        if (last_trip) break;
         const int b = b0 + lane;
         double lw = 0.0;
         bool listed = false;
@@ -299,7 +303,6 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_weights_L(WeightArgs a)
         }
         n_list += __builtin_popcountll(m);
     }
-    acc = kwl_flush<VARIANT == 0>(a, val, beam, n_list, b_done, a.B, acc, lane);
     if (lane == 0) a.w[p] = a.log_domain ? acc : dm_exp(acc);
     if (VARIANT == 1 && a.stats)
     {
