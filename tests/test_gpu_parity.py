@@ -392,6 +392,60 @@ def test_kernel_shape_and_order_follow_the_cloud_without_changing_a_bit(sa):
     f.close()
 
 
+def test_heading_buckets_sized_by_the_cloud_change_no_bit(sa, tmp_path):
+    """k_order_keys sizes the heading buckets of the pose-coherent order from the cloud's extent (round 3: 10 bits for a
+    converged cloud, 6 for a wide one).  A filter loop (wide cloud that converges over its steps, so that the bucket count
+    changes on the way) in three child processes: buckets sized by the cloud (default), fixed at 10 bits
+    (SLAM_PL_ORDER_ADAPT=0), and an explicit place-first order with 5 heading bits.  Weights of every step, selected indices and
+    final poses must be the same bits in all three, and the first step's weights equal the oracle's on a subset."""
+    import subprocess
+    import sys
+
+    code = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import _oracle as orc, slam_amd as sa
+free = orc.load_map("floor_plan"); g = (free * 255).astype(np.uint8); rows, cols = g.shape
+N, B, off = 30000, 120, [0.0, 30.0, 0.0]
+f = sa.Filter(N, rows, cols, seed=4242)
+f.set_map(g)
+f.seed_gaussian([520.0, 280.0, 0.4], [25.0, 25.0, 0.2])
+out = {}
+pose = [520.0, 280.0, 0.4]
+for step in range(6):
+    ang, dist = orc.make_scan(free, pose, off, B)
+    if step == 0:
+        out["x0"], out["y0"], out["th0"] = f.poses()
+        f.update_weights(ang, dist, 5.0, 500.0, off)
+        out["w_first"] = f.weights()
+    f.predict([2.5, 0.02, 0.02], [5e-4, 5e-4, 1e-2, 1e-2])
+    f.update(ang, dist, 5.0, 500.0, off)
+    out[f"w{step}"] = f.weights(); out[f"idx{step}"] = f.last_indices()
+out["x"], out["y"], out["th"] = f.poses()
+out["ang"], out["dist"] = orc.make_scan(free, [520.0, 280.0, 0.4], off, B)
+f.close()
+np.savez(sys.argv[3], **out)
+"""
+    root = os.path.dirname(HERE)
+    res = {}
+    for tag, env in (("adaptive", {}), ("fixed", {"SLAM_PL_ORDER_ADAPT": "0"}), ("place_first", {"SLAM_PL_ORDER": str(4 | (5 << 4) | (5 << 8))})):
+        path = str(tmp_path / f"{tag}.npz")
+        subprocess.run([sys.executable, "-c", code, root, HERE, path], check=True, env=dict(os.environ, **env), timeout=300)
+        res[tag] = np.load(path)
+    for k in res["fixed"].files:
+        for tag in ("adaptive", "place_first"):
+            a, b = res[tag][k], res["fixed"][k]
+            if a.dtype.kind == "f":
+                assert_bits(a, b, f"{tag} {k}")
+            else:
+                assert np.array_equal(a, b), f"{tag} {k}"
+    r = res["adaptive"]
+    g = (orc.load_map("floor_plan") * 255).astype(np.uint8)
+    sub = np.arange(0, r["x0"].size, 37)
+    ow, _ = orc.update_weights(r["x0"][sub], r["y0"][sub], r["th0"][sub], g, r["ang"], r["dist"], 5.0, 500.0, OFFSET, math=orc.DET, n_threads=8)
+    assert_bits(r["w_first"][sub], ow, "first weighting pass vs oracle")
+
+
 def test_one_chebyshev_plane_in_place_of_the_cone_planes(sa, tmp_path):
     """Maps too large for eight planes below 4 GiB get ONE plane of Chebyshev clearance (plane stride 0).  The choice is
     made when the map is set; SLAM_CONE_PLANES=0 forces it in a child process, whose weights and hits must equal the ones
