@@ -22,6 +22,10 @@ int main()
     {
         const double u = drand48();
         x[i] = i % 4 == 0 ? -8.0 * u : (i % 4 == 1 ? (u - 0.5) * 1400 : (i % 4 == 2 ? 0.1 + 0.2 * u : (u - 0.5) * 4));
+        // for the table-driven sincos: next to the multiples of pi/128 (its re-reduction), its hand-over at 16384, beyond
+        if (i % 16 == 5) x[i] = (double)(i % 4096 - 2048) * 0.02454369260617026 * (1.0 + (u - 0.5) * (i % 32 == 5 ? 1e-15 : 1e-9));
+        if (i % 16 == 9) x[i] = (u - 0.5) * (i % 32 == 9 ? 32800.0 : 4.2e6);
+        if (i % 16 == 13) x[i] = (u - 0.5) * 1e-12;
     }
     double *dx, *de, *dl, *ds, *dc;
     (void)hipMalloc(&dx, n * 8); (void)hipMalloc(&de, n * 8); (void)hipMalloc(&dl, n * 8); (void)hipMalloc(&ds, n * 8); (void)hipMalloc(&dc, n * 8);

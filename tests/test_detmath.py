@@ -20,6 +20,31 @@ def test_sincos_within_one_ulp(orc, fn, f):
     assert np.mean(orc.detmath(fn, x) != orc.libm(fn, x)) < 0.06
 
 
+@pytest.mark.parametrize("fn,f", [(0, np.sin), (1, np.cos)])
+def test_sincos_table_seams_zeros_and_hand_over(orc, fn, f):
+    """The table-driven sin / cos of round 3 (|x| < 16384): half a unit in the last place plus the final rounding's slack, also
+    where it is hardest: either side of the seams between table entries, next to the multiples of pi/128 (among them the zeros
+    of sin and cos, where the reduction is redone with more of pi), the band next to a zero entry (where the table's tail
+    times r counts), tiny arguments; the polynomial form beyond 16384 stays within one unit."""
+    h = np.pi / 128
+    k = np.arange(0, 700, dtype=np.float64)
+    x = np.concatenate([rng.uniform(-16384, 16384, 200000), rng.uniform(-8, 8, 200000),
+                        rng.uniform(0.5 * h, 1.5 * h, 50000), np.pi / 2 + rng.uniform(-2 * h, 2 * h, 50000), np.pi + rng.uniform(-2 * h, 2 * h, 50000)]
+                       + [(k + 0.5) * h * (1 + e) for e in (0.0, 1e-16, -1e-16, 1e-9, -1e-9)]
+                       + [k * h * (1 + e) for e in (0.0, 1.2e-16, -1.2e-16, 3e-13, -3e-13, 1e-8)]
+                       + [10.0 ** rng.uniform(-300, -2, 20000), -(10.0 ** rng.uniform(-20, -2, 20000)), [0.0, 16383.999999999998]])
+    assert ulp_err(orc.detmath(fn, x), x, f) < 0.502
+    z = orc.detmath(fn, [0.0, -0.0])
+    assert (z[0] == 0.0 and z[1] == 0.0 and np.signbit(z[1]) and not np.signbit(z[0])) if fn == 0 else (z[0] == 1.0 and z[1] == 1.0)
+    big = np.concatenate([rng.uniform(16384, 1048576, 50000), -rng.uniform(16384, 1048576, 50000), [16384.0, -16384.0]])
+    assert ulp_err(orc.detmath(fn, big), big, f) < 1.0
+    assert np.all(np.isnan(orc.detmath(fn, [np.inf, -np.inf, np.nan])))
+    # odd / even in the argument, bit for bit
+    y = rng.uniform(0, 40, 10000)
+    a, b = orc.detmath(fn, y), orc.detmath(fn, -y)
+    assert np.array_equal(a, -b if fn == 0 else b)
+
+
 def test_cos_half_pi_is_accurate(orc):
     assert orc.detmath(1, [np.pi / 2])[0] == pytest.approx(6.123233995736766e-17, rel=1e-15)
 
