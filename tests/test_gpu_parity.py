@@ -211,7 +211,8 @@ def test_weights_hostile_poses(sa, N, mapname, zmax):
     y[k:2 * k] = rng.choice([-1e6, 3e9, -5e9, 1e15, 2.0 ** 52, 0.0, -0.0], k)
     x[2 * k:3 * k] = np.floor(x[2 * k:3 * k])
     y[2 * k:3 * k] = np.floor(y[2 * k:3 * k])
-    th[3 * k:4 * k] = rng.choice([1e5, -1e5, 1e300, 0.0, np.pi / 2, -np.pi], k)
+    # (16384: where the table-driven sin / cos hands over to the polynomial form; multiples of pi/128: the table's own arguments)
+    th[3 * k:4 * k] = rng.choice([1e5, -1e5, 1e300, 0.0, np.pi / 2, -np.pi, 16383.999, -16384.0, 16384.5, 25735.9, 37 * np.pi / 128, -129 * np.pi / 128], k)
     ow, oxy, ocell, _ = orc.update_weights(x, y, th, g, ang, dist, 2.0, zmax, [0.5, 1.5, 0.1], want_hits=True, math=orc.DET)
     for shape in ("fast", "beam_lanes", "particle_lanes", "walk"):
         f = sa.Filter(N, rows, cols, raycaster=RAYCASTERS[shape])
