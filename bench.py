@@ -169,6 +169,15 @@ def physical_roofline(kernel_names, kernel_ms, f64_key):
                          "with 3.4 (profiles/ubench_r03.txt); SALU and memory instructions issue beside them; the clock under load may be below "
                          "the nominal 2.4 GHz, which makes both fractions lower bounds")
             out["valu"] = v
+            # each kernel by itself, from the committed profile alone (its instruction count over its own duration in the trace run
+            # of the same sources): the live figure above divides by the time of the whole group, launch-bound helpers included
+            per = {}
+            for name, k in zip(kernel_names, ks):
+                if "trace_avg_ns" in k and "sq" in k:
+                    per[name] = {"avg_ms_in_the_committed_trace": k["trace_avg_ns"] * 1e-6,
+                                 "valu_busy_frac": k["sq"]["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * CLOCK_HZ * k["trace_avg_ns"] * 1e-9)}
+            if per:
+                v["per_kernel_from_the_committed_profile"] = per
         return out
     except Exception:
         return None

@@ -195,6 +195,37 @@ def weights_traffic(base):
                 if a is not None:
                     sf[k], sr[k] = a, b
             out["kernels"][nf]["sq"], out["kernels"][nr]["sq"] = sf, sr
+    # the kernels' own durations in the trace runs (the timed steps of the headline run; the largest-grid launches of the
+    # secondary run), so that bench.py can state how busy each kernel keeps the vector ALUs by itself, beside the figure for
+    # the whole pass that it measures live
+    def trace_ns(db, like, steps=20, after=23, big_only=False):
+        cur = sqlite3.connect(db).cursor()
+        v = cur.execute("select end - start, grid_size from kernels where name like ? order by start", (like,)).fetchall() \
+            if "grid_size" in [r[1] for r in cur.execute("pragma table_info(kernels)")] else \
+            [(r[0], 0) for r in cur.execute("select end - start from kernels where name like ? order by start", (like,))]
+        if not v:
+            return None
+        if big_only:
+            big = max(g for _, g in v)
+            d = [t for t, g in v if g == big]
+        else:
+            d = [t for t, _ in v]
+            if len(d) >= steps + after:
+                d = d[-(steps + after):-after]
+        return sum(d) / len(d)
+    tr = glob.glob(os.path.join(base, "trace", "*_results.db"))
+    ts = glob.glob(os.path.join(base, "trace_sec", "*_results.db"))
+    if tr:
+        for name, like in (("k_rays_pl", "%k_rays_pl<5, false, false>%"), ("k_sum_lw", "%k_sum_lw%")):
+            t = trace_ns(tr[0], like)
+            if t and name in out["kernels"]:
+                out["kernels"][name]["trace_avg_ns"] = t
+    if ts:
+        for name, like in (("weighting kernel of the 16384^2 shard (k_weights_L<0>, 12.5 M particles)", "%k_weights_L<0,%"),
+                           ("k_weights_S2F (125 000-particle shard)", "%k_weights_S2F%")):
+            t = trace_ns(ts[0], like, big_only=True)
+            if t and name in out["kernels"]:
+                out["kernels"][name]["trace_avg_ns"] = t
     # bench.py quotes hbm_bytes_per_launch only while the kernel sources are the ones measured here
     import hashlib
     h = hashlib.sha256()
