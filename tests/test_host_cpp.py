@@ -152,14 +152,14 @@ def test_cpp_shim_under_host_sanitizers(tmp_path, storage):
 
 @pytest.mark.gpu
 def test_detmath_on_the_device_equals_the_host_bit_for_bit():
-    """tests/host_cpp/detmath_devcheck.hip: dm_exp, dm_log (table driven since round 3) and dm_sincos evaluated by a kernel and by
+    """tests/host_cpp/detmath_devcheck.hip: dm_exp, dm_log, dm_sincos (table driven since round 3) and dm_sqrt (the compiler's expansion on the device) evaluated by a kernel and by
     the host on 4 M arguments (likelihood range, the whole exponent range, near 1): the same bits, which is what lets the CPU
     oracle stand in for the kernels' arithmetic."""
     exe = os.path.join(HERE, "host_cpp", "detmath_devcheck")
     if not os.path.exists(exe):
         pytest.skip("detmath_devcheck absent (make -C tests/host_cpp detmath_devcheck)")
     got = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert got.returncode == 0 and "exp differs 0, log differs 0, sincos differs 0" in got.stdout, got.stdout + got.stderr
+    assert got.returncode == 0 and "exp differs 0, log differs 0, sincos differs 0, sqrt differs 0" in got.stdout, got.stdout + got.stderr
 
 
 @pytest.mark.gpu
